@@ -1,0 +1,622 @@
+// sw_kernels.hpp -- CDNA4 (gfx950) kernels of the batched multi-RHS Schwinger engine.
+//
+// Data layout in HBM: every level vector is a row-major [n][nbp] array of
+// complex128 with the right-hand side (probe) index fastest; nbp is a multiple of 64 so one
+// wave64 reads/writes one 1-KiB contiguous row segment (16 B per lane) per instruction.
+// Level 0 rows are ordered [parity][site-in-parity][spin]  (even-odd lattice layout),
+// coarse levels keep the reference's row order.  In every kernel lane == probe, so per-probe
+// reductions run down the rows inside a thread and need no cross-lane traffic; cross-wave
+// sums go through LDS, cross-workgroup sums through a deterministic two-stage reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace swk {
+
+typedef double2 cplx;
+
+#define SW_WAVE 64
+#define SW_BLOCK 256
+#define SW_WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ cplx cmake(double a, double b) { cplx r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  return cmake(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+// conj(a) * b
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) {
+  return cmake(fma(a.x, b.x, a.y * b.y), fma(a.x, b.y, -a.y * b.x));
+}
+// acc += a*b
+__device__ __forceinline__ void cfma(cplx& acc, cplx a, cplx b) {
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.y = fma(a.y, b.x, acc.y);
+}
+// acc += conj(a)*b
+__device__ __forceinline__ void cfmac(cplx& acc, cplx a, cplx b) {
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.x = fma(a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.y = fma(-a.y, b.x, acc.y);
+}
+// i*a, -i*a
+__device__ __forceinline__ cplx cmuli(cplx a) { return cmake(-a.y, a.x); }
+__device__ __forceinline__ cplx cmulmi(cplx a) { return cmake(a.y, -a.x); }
+
+// Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH, Workgroup dispatch); this
+// bijective remap hands each XCD one contiguous range of logical blocks so that neighbouring
+// lattice rows are served from the same 4-MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  return (nblk % 8 == 0) ? (b % 8) * (nblk / 8) + (b / 8) : b;
+}
+
+// ------------------------------------------------------------------------------------------
+// Level-0 operator: U(1) Wilson-Schwinger stencil  A = S + m  (replaces the CSR
+// SpMV of multigrid.py:552-557 / matrix.py:21-29).  One wave = one lattice site x 64 probes.
+//   (S psi)(n) = 4 psi(n) - [ (1-s1) U1(n) psi(n+x) + (1+s1) U1*(n-x) psi(n-x)
+//                           + (1-s2) U2(n) psi(n+y) + (1+s2) U2*(n-y) psi(n-y) ]
+// MODE 0: Y = A X      MODE 1: Y = B - A X
+// DOTS: also accumulate, per probe, d0 = sum conj(Q) * Y and d1 = sum |Y|^2 over the rows of
+// this workgroup (Q = B argument when MODE 0 ... see k_stencil body), written to `partial`.
+// ------------------------------------------------------------------------------------------
+struct StencilArgs {
+  int L;          // lattice extent (even)
+  int Vh;         // L*L/2
+  double diag;    // 4 + mass
+  const cplx* U1; // [L*L] site index y*L+x
+  const cplx* U2;
+  int nbp;
+  int sites_per_wave;  // consecutive x-sites handled by one wave
+};
+
+__device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
+  // row of spin 0 of site (x,y) in the even-odd layout; spin 1 is the next row
+  int par = (x + y) & 1;
+  int sh = (y * L + x) >> 1;
+  return ((size_t)par * Vh + sh) * 2;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X,
+                                                      const cplx* __restrict__ B,
+                                                      cplx* __restrict__ Y, StencilArgs a,
+                                                      int blocks_per_chunk) {
+  const int nblk = gridDim.x;
+  const int bb = xcd_remap(blockIdx.x, nblk);
+  const int chunk = bb / blocks_per_chunk;
+  const int sg = bb % blocks_per_chunk;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int L = a.L;
+  const int nbp = a.nbp;
+  const size_t col = (size_t)chunk * 64 + lane;
+  const int spw = a.sites_per_wave;
+  const int site0 = __builtin_amdgcn_readfirstlane((sg * SW_WAVES_PER_BLOCK + wave) * spw);
+  if (site0 >= L * L) return;
+  const int y = site0 / L;
+  const int x0 = site0 % L;
+  const int yp = (y + 1 == L) ? 0 : y + 1;
+  const int ym = (y == 0) ? L - 1 : y - 1;
+  const cplx* Xc = X + col;
+  for (int s = 0; s < spw; ++s) {
+    const int x = x0 + s;  // spw divides L, so the run never leaves the row
+    const int xp = (x + 1 == L) ? 0 : x + 1;
+    const int xm = (x == 0) ? L - 1 : x - 1;
+    const size_t r_c = eo_row(x, y, L, a.Vh);
+    const size_t r_xp = eo_row(xp, y, L, a.Vh);
+    const size_t r_xm = eo_row(xm, y, L, a.Vh);
+    const size_t r_yp = eo_row(x, yp, L, a.Vh);
+    const size_t r_ym = eo_row(x, ym, L, a.Vh);
+    // issue all ten loads before any use
+    const cplx c0 = Xc[r_c * nbp], c1 = Xc[(r_c + 1) * nbp];
+    const cplx a0 = Xc[r_xp * nbp], a1 = Xc[(r_xp + 1) * nbp];
+    const cplx b0 = Xc[r_xm * nbp], b1 = Xc[(r_xm + 1) * nbp];
+    const cplx d0 = Xc[r_yp * nbp], d1 = Xc[(r_yp + 1) * nbp];
+    const cplx e0 = Xc[r_ym * nbp], e1 = Xc[(r_ym + 1) * nbp];
+    const int n = y * L + x;
+    const cplx u1 = a.U1[n];
+    const cplx u1m = a.U1[y * L + xm];
+    const cplx u2 = a.U2[n];
+    const cplx u2m = a.U2[ym * L + x];
+    // +x: (1-s1) -> [t,-t], t = psi0 - psi1
+    const cplx tx = cmul(u1, csub(a0, a1));
+    // -x: (1+s1) -> [t, t], t = psi0 + psi1, link conj(U1(n-x))
+    const cplx txm = cmulc(u1m, cadd(b0, b1));
+    // +y: (1-s2) -> [t, -i t], t = psi0 + i psi1
+    const cplx ty = cmul(u2, cadd(d0, cmuli(d1)));
+    // -y: (1+s2) -> [t, i t], t = psi0 - i psi1, link conj(U2(n-y))
+    const cplx tym = cmulc(u2m, csub(e0, cmuli(e1)));
+    cplx h0 = cadd(cadd(tx, txm), cadd(ty, tym));
+    cplx h1 = cadd(csub(txm, tx), cmuli(csub(tym, ty)));
+    cplx o0 = cmake(fma(a.diag, c0.x, -h0.x), fma(a.diag, c0.y, -h0.y));
+    cplx o1 = cmake(fma(a.diag, c1.x, -h1.x), fma(a.diag, c1.y, -h1.y));
+    if (MODE == 1) {
+      const cplx q0 = B[r_c * nbp + col], q1 = B[(r_c + 1) * nbp + col];
+      o0 = csub(q0, o0);
+      o1 = csub(q1, o1);
+    }
+    Y[r_c * nbp + col] = o0;
+    Y[(r_c + 1) * nbp + col] = o1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Grouped-ELL operator: coarse operators A_l, prolongators P_l, restrictors R_l = P_l^H, the
+// dense coarsest inverse and the MLMC rhs maps.  G consecutive rows share one list of K column
+// indices (the dense-block structure of SURVEY 3.4); one wave = one row group x 64 probes, each
+// X row is loaded once and used G times with wave-uniform (scalar) coefficients.
+//   cols [ngroups][K]   vals [ngroups][K][G]   (padding: col 0, val 0)
+// MODE 0: Y = A X      MODE 1: Y = B - A X      MODE 2: Y = B + A X
+// ------------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
+                                                  const cplx* __restrict__ vals, int K,
+                                                  int ngroups, const int* __restrict__ rowmap,
+                                                  const cplx* __restrict__ X,
+                                                  const cplx* __restrict__ B,
+                                                  cplx* __restrict__ Y, int nbp) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int grp = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + wave);
+  if (grp >= ngroups) return;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int* c = cols + (size_t)grp * K;
+  const cplx* v = vals + (size_t)grp * K * G;
+  cplx acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = cmake(0.0, 0.0);
+  const cplx* Xc = X + col;
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) {
+    const int j = c[k];
+    const cplx x = Xc[(size_t)j * nbp];
+#pragma unroll
+    for (int g = 0; g < G; ++g) cfma(acc[g], v[(size_t)k * G + g], x);
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    // rowmap (optional): output row of logical row grp*G+g (level-0 even-odd permutation)
+    const size_t row = rowmap ? (size_t)rowmap[(size_t)grp * G + g] : (size_t)grp * G + g;
+    cplx o = acc[g];
+    if (MODE == 1) o = csub(B[row * nbp + col], o);
+    if (MODE == 2) o = cadd(B[row * nbp + col], o);
+    Y[row * nbp + col] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pack / unpack between the reference's host layout ([probe][natural index], probe-major) and
+// the engine layout ([internal row][probe]).  rowmap[natural] = internal row (NULL: identity).
+// ------------------------------------------------------------------------------------------
+// probes: int8 +-1  ->  complex
+__global__ __launch_bounds__(SW_BLOCK) void k_pack_i8(const int8_t* __restrict__ src, int nb,
+                                                      int n, const int* __restrict__ rowmap,
+                                                      cplx* __restrict__ dst, int nbp) {
+  // tile of 64 natural indices x 64 probes through LDS so both sides are coalesced
+  __shared__ int8_t tile[64][65];
+  const int i0 = blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int jj = ty; jj < 64; jj += 4) {
+    const int j = j0 + jj, i = i0 + tx;
+    tile[jj][tx] = (j < nb && i < n) ? src[(size_t)j * n + i] : (int8_t)0;
+  }
+  __syncthreads();
+  for (int ii = ty; ii < 64; ii += 4) {
+    const int i = i0 + ii;
+    if (i < n) {
+      const size_t row = rowmap ? (size_t)rowmap[i] : (size_t)i;
+      dst[row * nbp + j0 + tx] = cmake((double)tile[tx][ii], 0.0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_pack_c(const cplx* __restrict__ src, int nb, int n,
+                                                     const int* __restrict__ rowmap,
+                                                     cplx* __restrict__ dst, int nbp) {
+  __shared__ cplx tile[64][65];
+  const int i0 = blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int jj = ty; jj < 64; jj += 4) {
+    const int j = j0 + jj, i = i0 + tx;
+    tile[jj][tx] = (j < nb && i < n) ? src[(size_t)j * n + i] : cmake(0.0, 0.0);
+  }
+  __syncthreads();
+  for (int ii = ty; ii < 64; ii += 4) {
+    const int i = i0 + ii;
+    if (i < n) {
+      const size_t row = rowmap ? (size_t)rowmap[i] : (size_t)i;
+      dst[row * nbp + j0 + tx] = tile[tx][ii];
+    }
+  }
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_unpack_c(const cplx* __restrict__ src, int nbp,
+                                                       int n, const int* __restrict__ rowmap,
+                                                       cplx* __restrict__ dst, int nb) {
+  __shared__ cplx tile[64][65];
+  const int i0 = blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int ii = ty; ii < 64; ii += 4) {
+    const int i = i0 + ii;
+    if (i < n) {
+      const size_t row = rowmap ? (size_t)rowmap[i] : (size_t)i;
+      tile[ii][tx] = src[row * nbp + j0 + tx];
+    }
+  }
+  __syncthreads();
+  for (int jj = ty; jj < 64; jj += 4) {
+    const int j = j0 + jj, i = i0 + tx;
+    if (j < nb && i < n) dst[(size_t)j * n + i] = tile[tx][jj];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched BLAS-1.  All of them: lane == probe, grid.y == 64-probe chunk.
+// ------------------------------------------------------------------------------------------
+#define SW_MAXK 49   // SW_MAX_KRYLOV + 1
+
+struct PtrList {
+  const cplx* p[SW_MAXK];
+};
+
+// partial[(blockIdx.x*K + k)*nbp + col] = sum over this block's rows of conj(V_k[r]) * W[r]
+template <int KT>
+__global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrList V, int K, const cplx* __restrict__ W,
+                                                       int n, int nbp, int rows_per_block,
+                                                       cplx* __restrict__ partial) {
+  __shared__ cplx red[3][8][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  cplx acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) acc[k] = cmake(0.0, 0.0);
+#pragma unroll 2
+  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
+    const size_t off = (size_t)r * nbp + col;
+    const cplx w = W[off];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < K) cfmac(acc[k], V.p[k][off], w);
+  }
+  // cross-wave reduction, 8 accumulators at a time
+  for (int kb = 0; kb < KT; kb += 8) {
+    if (kb >= K) break;
+    if (wave > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (kb + k < KT) red[wave - 1][k][lane] = acc[kb + k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (kb + k < KT && kb + k < K) {
+          cplx s = acc[kb + k];
+          s = cadd(s, red[0][k][lane]);
+          s = cadd(s, red[1][k][lane]);
+          s = cadd(s, red[2][k][lane]);
+          partial[((size_t)blockIdx.x * K + kb + k) * nbp + col] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[k*nbp + col] = sum_p partial[(p*K + k)*nbp + col]
+__global__ __launch_bounds__(SW_BLOCK) void k_reduce_partials(const cplx* __restrict__ partial,
+                                                              int P, int K, int nbp,
+                                                              cplx* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * nbp) return;
+  const int k = idx / nbp, col = idx % nbp;
+  cplx s = cmake(0.0, 0.0);
+  for (int p = 0; p < P; ++p) s = cadd(s, partial[((size_t)p * K + k) * nbp + col]);
+  out[(size_t)k * nbp + col] = s;
+}
+
+// Wout[r] = Win[r] + sign * sum_k coef[k][col] * V_k[r]; optionally partial |Wout|^2 sums
+// (as the real part of a cplx partial, layout as k_multidot with K = 1).
+template <int KT, bool NORM>
+__global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrList V, int K,
+                                                        const cplx* __restrict__ coef, double sign,
+                                                        const cplx* __restrict__ Win,
+                                                        cplx* __restrict__ Wout, int n, int nbp,
+                                                        int rows_per_block,
+                                                        cplx* __restrict__ partial) {
+  __shared__ double redn[3][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  cplx c[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    c[k] = cmake(0.0, 0.0);
+    if (k < K) {
+      const cplx t = coef[(size_t)k * nbp + col];
+      c[k] = cmake(sign * t.x, sign * t.y);
+    }
+  }
+  double nrm = 0.0;
+#pragma unroll 2
+  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
+    const size_t off = (size_t)r * nbp + col;
+    cplx w = Win[off];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < K) cfma(w, c[k], V.p[k][off]);
+    Wout[off] = w;
+    if (NORM) nrm = fma(w.x, w.x, fma(w.y, w.y, nrm));
+  }
+  if (NORM) {
+    if (wave > 0) redn[wave - 1][lane] = nrm;
+    __syncthreads();
+    if (wave == 0) {
+      nrm += redn[0][lane];
+      nrm += redn[1][lane];
+      nrm += redn[2][lane];
+      partial[(size_t)blockIdx.x * nbp + col] = cmake(nrm, 0.0);
+    }
+  }
+}
+
+// MR smoother update (one pass):  X += alpha*R ;  R -= alpha*T     alpha per probe
+__global__ __launch_bounds__(SW_BLOCK) void k_mr_update(const cplx* __restrict__ alpha,
+                                                        cplx* __restrict__ X, cplx* __restrict__ R,
+                                                        const cplx* __restrict__ T, int n, int nbp,
+                                                        int rows_per_block) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  const cplx al = alpha[col];
+#pragma unroll 2
+  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
+    const size_t off = (size_t)r * nbp + col;
+    cplx x = X[off], rr = R[off];
+    const cplx t = T[off];
+    cfma(x, al, rr);
+    cfma(rr, cmake(-al.x, -al.y), t);
+    X[off] = x;
+    R[off] = rr;
+  }
+}
+
+// dst[r] = s[col] * src[r]   (s real per probe, stored as the .x of a cplx array)
+__global__ __launch_bounds__(SW_BLOCK) void k_scale(const cplx* __restrict__ s,
+                                                    const cplx* __restrict__ src,
+                                                    cplx* __restrict__ dst, int n, int nbp,
+                                                    int rows_per_block) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  const double f = s[col].x;
+#pragma unroll 2
+  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
+    const size_t off = (size_t)r * nbp + col;
+    const cplx v = src[off];
+    dst[off] = cmake(f * v.x, f * v.y);
+  }
+}
+
+// dst[r] = src[srcrow[r]]  (row gather: the Pperm^T index shift in the internal row order)
+__global__ __launch_bounds__(SW_BLOCK) void k_gather_rows(const int* __restrict__ srcrow,
+                                                          const cplx* __restrict__ src,
+                                                          cplx* __restrict__ dst, int n, int nbp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r = blockIdx.x * SW_WAVES_PER_BLOCK + wave;
+  if (r >= n) return;
+  const int s = srcrow ? srcrow[r] : r;
+  dst[(size_t)r * nbp + col] = src[(size_t)s * nbp + col];
+}
+
+// ------------------------------------------------------------------------------------------
+// Deflation (utils.py:221-225):  c = U^H x  (partials), then  out[r] = x[s] - sum_k U[s][k] c[k]
+// with s = srcrow[r] (fused Pperm^T gather).  U is [n][kd] row-major, coefficients are
+// wave-uniform so they ride the scalar path.
+// ------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(SW_BLOCK) void k_defl_dots(const cplx* __restrict__ U, int ldu,
+                                                        int kd, const cplx* __restrict__ X, int n,
+                                                        int nbp, int rows_per_block,
+                                                        cplx* __restrict__ partial) {
+  __shared__ cplx red[3][8][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  cplx acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) acc[k] = cmake(0.0, 0.0);
+  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
+    const int ru = __builtin_amdgcn_readfirstlane(r);
+    const cplx x = X[(size_t)ru * nbp + col];
+    const cplx* u = U + (size_t)ru * ldu;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < kd) cfmac(acc[k], u[k], x);
+  }
+  for (int kb = 0; kb < KT; kb += 8) {
+    if (kb >= kd) break;
+    if (wave > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (kb + k < KT) red[wave - 1][k][lane] = acc[kb + k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (kb + k < KT && kb + k < kd) {
+          cplx s = acc[kb + k];
+          s = cadd(s, red[0][k][lane]);
+          s = cadd(s, red[1][k][lane]);
+          s = cadd(s, red[2][k][lane]);
+          partial[((size_t)blockIdx.x * kd + kb + k) * nbp + col] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_defl_apply(const cplx* __restrict__ U, int kd,
+                                                         const cplx* __restrict__ c,
+                                                         const int* __restrict__ srcrow,
+                                                         const cplx* __restrict__ X,
+                                                         cplx* __restrict__ out, int n, int nbp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + wave);
+  if (r >= n) return;
+  const int s = srcrow ? srcrow[r] : r;
+  cplx x = X[(size_t)s * nbp + col];
+  const cplx* u = U + (size_t)s * kd;
+#pragma unroll 4
+  for (int k = 0; k < kd; ++k) {
+    const cplx ck = c[(size_t)k * nbp + col];
+    cfma(x, cmake(-u[k].x, -u[k].y), ck);
+  }
+  out[(size_t)r * nbp + col] = x;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-probe scalar kernels of the batched flexible GMRES (one thread per probe).
+// Storage: H [(m+1)][m][nbp], cs [m][nbp] (.x), sn [m][nbp], g [(m+1)][nbp].
+// ------------------------------------------------------------------------------------------
+struct FgScalars {
+  cplx* H;
+  cplx* cs;
+  cplx* sn;
+  cplx* g;
+  cplx* y;        // [m][nbp]
+  cplx* normb;    // [nbp] .x
+  cplx* relres;   // [nbp] .x
+  cplx* scale;    // [nbp] .x  (1/beta or 1/h_{j+1,j})
+  int* iters;     // [nbp] iteration at which the probe first met tol (-1: not yet)
+  int* notconv;   // [1] number of probes still above tol
+  int m;
+  int nbp;
+};
+
+// start of a cycle: beta = sqrt(d[col].x);  first cycle also fixes normb
+__global__ void k_fg_begin(FgScalars s, const cplx* __restrict__ d, int first_cycle, double tol) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= s.nbp) return;
+  const double beta = sqrt(fmax(d[col].x, 0.0));
+  if (first_cycle) {
+    s.normb[col] = cmake(beta, 0.0);
+    s.iters[col] = (beta > 0.0) ? -1 : 0;
+    s.relres[col] = cmake(beta > 0.0 ? 1.0 : 0.0, 0.0);
+  }
+  s.g[col] = cmake(beta, 0.0);
+  s.scale[col] = cmake(beta > 0.0 ? 1.0 / beta : 0.0, 0.0);
+}
+
+// column j of the Hessenberg matrix: h = h1 + h2 (two Gram-Schmidt passes), h_{j+1,j} = sqrt(nrm2)
+__global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
+                          const cplx* __restrict__ h2, const cplx* __restrict__ nrm2, double tol,
+                          int iter_base) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= s.nbp) return;
+  const int m = s.m, nbp = s.nbp;
+  const double hn = sqrt(fmax(nrm2[col].x, 0.0));
+  s.scale[col] = cmake(hn > 0.0 ? 1.0 / hn : 0.0, 0.0);
+  // apply the previous rotations
+  cplx hk = cadd(h1[col], h2[col]);
+  for (int k = 0; k < j; ++k) {
+    const cplx hk1 = cadd(h1[(size_t)(k + 1) * nbp + col], h2[(size_t)(k + 1) * nbp + col]);
+    const double c = s.cs[(size_t)k * nbp + col].x;
+    const cplx sn = s.sn[(size_t)k * nbp + col];
+    // [ c  sn ; -conj(sn)  c ]
+    cplx t = cmake(c * hk.x, c * hk.y);
+    cfma(t, sn, hk1);
+    cplx u = cmake(c * hk1.x, c * hk1.y);
+    cfma(u, cmake(-sn.x, sn.y), hk);
+    s.H[((size_t)k * m + j) * nbp + col] = t;
+    hk = u;
+  }
+  // new rotation annihilating h_{j+1,j} = hn
+  const double habs = sqrt(hk.x * hk.x + hk.y * hk.y);
+  const double dnm = sqrt(habs * habs + hn * hn);
+  double c;
+  cplx sn;
+  if (dnm == 0.0) {
+    c = 1.0;
+    sn = cmake(0.0, 0.0);
+  } else if (habs == 0.0) {
+    c = 0.0;
+    sn = cmake(1.0, 0.0);
+  } else {
+    c = habs / dnm;
+    const double f = hn / (habs * dnm);
+    sn = cmake(hk.x * f, hk.y * f);  // (a/|a|) * conj(b)/d, b = hn real
+  }
+  s.cs[(size_t)j * nbp + col] = cmake(c, 0.0);
+  s.sn[(size_t)j * nbp + col] = sn;
+  cplx hjj = cmake(c * hk.x, c * hk.y);
+  cfma(hjj, sn, cmake(hn, 0.0));
+  s.H[((size_t)j * m + j) * nbp + col] = hjj;
+  const cplx gj = s.g[(size_t)j * nbp + col];
+  s.g[(size_t)(j + 1) * nbp + col] = cmul(cmake(-sn.x, sn.y), gj);
+  s.g[(size_t)j * nbp + col] = cmake(c * gj.x, c * gj.y);
+  const cplx gn = s.g[(size_t)(j + 1) * nbp + col];
+  const double nb_ = s.normb[col].x;
+  const double rr = (nb_ > 0.0) ? sqrt(gn.x * gn.x + gn.y * gn.y) / nb_ : 0.0;
+  s.relres[col] = cmake(rr, 0.0);
+  if (s.iters[col] < 0) {
+    if (rr < tol) s.iters[col] = iter_base + j + 1;
+    else atomicAdd(s.notconv, 1);
+  }
+}
+
+// y = H(0:k,0:k)^-1 g(0:k) per probe
+__global__ void k_fg_solve(FgScalars s, int k) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= s.nbp) return;
+  const int m = s.m, nbp = s.nbp;
+  for (int i = k - 1; i >= 0; --i) {
+    cplx t = s.g[(size_t)i * nbp + col];
+    for (int l = i + 1; l < k; ++l) {
+      const cplx hl = s.H[((size_t)i * m + l) * nbp + col];
+      const cplx yl = s.y[(size_t)l * nbp + col];
+      cfma(t, cmake(-hl.x, -hl.y), yl);
+    }
+    const cplx hii = s.H[((size_t)i * m + i) * nbp + col];
+    const double dd = hii.x * hii.x + hii.y * hii.y;
+    cplx yi = cmake(0.0, 0.0);
+    if (dd > 0.0) yi = cmake((t.x * hii.x + t.y * hii.y) / dd, (t.y * hii.x - t.x * hii.y) / dd);
+    s.y[(size_t)i * nbp + col] = yi;
+  }
+}
+
+// MR step length alpha = <T,R>/<T,T> from d0 = <R,T> (= sum conj(R) T), d1 = <T,T>
+__global__ void k_mr_alpha(const cplx* __restrict__ d, int nbp, cplx* __restrict__ alpha) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= nbp) return;
+  const cplx d0 = d[col];
+  const double d1 = d[(size_t)nbp + col].x;
+  alpha[col] = (d1 > 0.0) ? cmake(d0.x / d1, -d0.y / d1) : cmake(0.0, 0.0);
+}
+
+// final estimates: e = a - b (b may be NULL)
+__global__ void k_est_combine(const cplx* __restrict__ a, const cplx* __restrict__ b, int nbp,
+                              cplx* __restrict__ e) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= nbp) return;
+  e[col] = b ? csub(a[col], b[col]) : a[col];
+}
+
+}  // namespace swk

@@ -1,0 +1,114 @@
+"""Probe sharding across GPUs: one process per GPU, replicated operands,
+contiguous probe ranges per rank, ONE small collective per round.
+
+Every rank draws the SAME seeded probe stream and keeps only its contiguous slice, so the
+stream position of probe k is identical to the single-GPU run.  After a round the ranks
+all-gather the 16-byte per-probe estimates (so the sequential stopping rule of
+stoch_trace.py:137-154 can be replayed identically everywhere) and all-reduce the four
+running statistics {sum Re e, sum Im e, sum |e|^2, count}.  ``torch.distributed`` supplies
+the transport: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in CPU tests.
+"""
+import numpy as np
+
+
+class Comm:
+    """Trivial single-process communicator."""
+    world = 1
+    rank = 0
+
+    def my_slice(self, count):
+        return 0, count
+
+    def allgather(self, arrays, count):
+        return arrays
+
+    def allreduce_stats(self, stats):
+        return np.asarray(stats, dtype=np.float64)
+
+    def barrier(self):
+        pass
+
+
+class TorchComm(Comm):
+    """Communicator over an initialised torch.distributed process group."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as td
+        if not td.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._torch = torch
+        self._td = td
+        self.world = td.get_world_size()
+        self.rank = td.get_rank()
+        if device is None:
+            device = "cuda" if td.get_backend() == "nccl" else "cpu"
+        self.device = device
+
+    def my_slice(self, count):
+        lo = (self.rank * count) // self.world
+        hi = ((self.rank + 1) * count) // self.world
+        return lo, hi
+
+    def allgather(self, arrays, count):
+        """arrays: list of 1-D float64/complex128/int arrays holding this rank's slice of a
+        round of `count` probes; returns the full-length arrays in probe order."""
+        torch, td = self._torch, self._td
+        out = []
+        sizes = [((r + 1) * count) // self.world - (r * count) // self.world
+                 for r in range(self.world)]
+        width = max(sizes)
+        for a in arrays:
+            a = np.asarray(a)
+            is_c = np.iscomplexobj(a)
+            loc = np.zeros((width, 2), dtype=np.float64)
+            if is_c:
+                loc[:a.size, 0] = a.real
+                loc[:a.size, 1] = a.imag
+            else:
+                loc[:a.size, 0] = a
+            t = torch.from_numpy(loc).to(self.device)
+            bufs = [torch.empty_like(t) for _ in range(self.world)]
+            td.all_gather(bufs, t)
+            parts = []
+            for r in range(self.world):
+                b = bufs[r].cpu().numpy()[:sizes[r]]
+                parts.append(b[:, 0] + 1j * b[:, 1] if is_c else b[:, 0].astype(a.dtype))
+            out.append(np.concatenate(parts))
+        return out
+
+    def allreduce_stats(self, stats):
+        torch, td = self._torch, self._td
+        t = torch.tensor(np.asarray(stats, dtype=np.float64), dtype=torch.float64,
+                         device=self.device)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def barrier(self):
+        self._td.barrier()
+
+
+def default_comm():
+    """TorchComm when a process group with more than one rank exists, else the trivial one."""
+    try:
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+            return TorchComm()
+    except Exception:
+        pass
+    return Comm()
+
+
+def local_stats(ests):
+    """{sum Re e, sum Im e, sum |e|^2, n} of a set of per-probe estimates."""
+    e = np.asarray(ests, dtype=np.complex128)
+    return np.array([e.real.sum(), e.imag.sum(), (np.abs(e) ** 2).sum(), float(e.size)])
+
+
+def mean_and_population_std(stats):
+    """Mean and population standard deviation (stoch_trace.py:143-145) from reduced stats:
+    var = sum|e|^2/n - |mean|^2."""
+    s_re, s_im, s_abs2, n = stats
+    mean = complex(s_re, s_im) / n
+    var = max(s_abs2 / n - abs(mean) ** 2, 0.0)
+    return mean, float(np.sqrt(var))

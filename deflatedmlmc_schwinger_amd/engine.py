@@ -1,0 +1,369 @@
+"""ctypes binding of the C ABI in ``include/schwinger_hip.h`` (libschwinger_hip.so).
+
+The library is the product's only compute path.  If it is missing, or no HIP
+device is visible, construction of :class:`Engine` raises -- there is no CPU
+fallback in this package (the NumPy restatement under ``oracle/`` is test
+infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libschwinger_hip.so")
+
+MODE_HUTCHINSON = 0
+MODE_MLMC = 1
+MODE_MLMC_SKIP = 2
+
+TIMER_NAMES = ("mvm", "defl", "P", "R", "axpy", "dots", "coarsest", "other")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load the C-ABI library (raises EngineError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "HIP engine library not built: %s is missing (run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` or `make -C deflatedmlmc_schwinger_amd/csrc`)"
+            % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise EngineError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    P = C.POINTER
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("sw_create", i32, P(vp), i32)
+    sig("sw_destroy", i32, vp)
+    sig("sw_last_error", C.c_char_p, vp)
+    sig("sw_device_count", i32)
+    sig("sw_version", C.c_char_p)
+    sig("sw_hier_begin", i32, vp, i32, i32)
+    sig("sw_set_lattice", i32, vp, i32, i32, dbl, vp, vp)
+    sig("sw_set_csr", i32, vp, i32, i32, i32, vp, vp, vp)
+    sig("sw_set_transfer", i32, vp, i32, i32, i32, i32, vp, vp, vp)
+    sig("sw_set_coarsest_inv", i32, vp, i32, i32, vp)
+    sig("sw_set_cycle", i32, vp, i32, i32, i32, i32, i32)
+    sig("sw_hier_end", i32, vp, i32)
+    sig("sw_set_deflation", i32, vp, i32, vp)
+    sig("sw_set_perm", i32, vp, i32, i64)
+    sig("sw_set_rhsmap", i32, vp, i32, i32, vp, vp, vp)
+    sig("sw_set_solver", i32, vp, i32, i32)
+    sig("sw_apply_dirac", i32, vp, i32, i32, i32, vp, vp)
+    sig("sw_restrict", i32, vp, i32, i32, i32, vp, vp)
+    sig("sw_prolong", i32, vp, i32, i32, i32, vp, vp)
+    sig("sw_coarsest", i32, vp, i32, i32, vp, vp)
+    sig("sw_vcycle", i32, vp, i32, i32, i32, vp, vp)
+    sig("sw_solve", i32, vp, i32, i32, i32, vp, vp, dbl, i32, vp, vp)
+    sig("sw_hutch_batch", i32, vp, i32, i32, i32, vp, dbl, i32, vp, vp)
+    sig("sw_probes_upload", i32, vp, i32, i32, vp)
+    sig("sw_hutch_run", i32, vp, i32, i32, dbl, i32)
+    sig("sw_sync", i32, vp)
+    sig("sw_hutch_fetch", i32, vp, vp, vp)
+    sig("sw_bench_dirac", i32, vp, i32, i32, i32, i32, P(dbl))
+    sig("sw_set_profiling", i32, vp, i32)
+    sig("sw_timers", i32, vp, P(dbl))
+    sig("sw_timers_reset", i32, vp)
+    sig("sw_launch_count", i32, vp, P(i64))
+    sig("sw_mt_create", vp, C.c_uint32)
+    sig("sw_mt_destroy", None, vp)
+    sig("sw_mt_skip", None, vp, C.c_uint64)
+    sig("sw_mt_raw", None, vp, C.c_uint64, vp)
+    sig("sw_mt_rademacher", None, vp, C.c_uint64, vp)
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
+    "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
+    "sw_hier_end", "sw_set_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver",
+    "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
+    "sw_hutch_batch", "sw_probes_upload", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
+    "sw_bench_dirac", "sw_set_profiling", "sw_timers", "sw_timers_reset", "sw_launch_count",
+    "sw_mt_create", "sw_mt_destroy", "sw_mt_skip", "sw_mt_raw", "sw_mt_rademacher",
+)
+
+
+def device_count():
+    return int(load_library().sw_device_count())
+
+
+def _c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _csr_parts(M):
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    indptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+    data = _c128(M.data)
+    return M.shape, indptr, indices, data
+
+
+class Engine:
+    """One handle = one GPU + one stream.  Vectors passed in and out are NumPy arrays in the
+    reference ordering, shape (n,) or (nb, n) (one row per right-hand side)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.sw_create(C.byref(self._h), int(device))
+        if rc != 0:
+            msg = self._lib.sw_last_error(None)
+            self._h = None
+            raise EngineError("sw_create failed: %s" % (msg.decode() if msg else "unknown"))
+        self.device = int(device)
+        self.level_sizes = {}
+
+    # -- plumbing --------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self._lib.sw_last_error(self._h)
+            raise EngineError("%s failed: %s" % (what, msg.decode() if msg else "unknown"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- operands --------------------------------------------------------------------------
+    def hier_begin(self, hid, nlevels):
+        self._chk(self._lib.sw_hier_begin(self._h, hid, nlevels), "sw_hier_begin")
+        self.level_sizes[hid] = [0] * nlevels
+
+    def set_lattice(self, hid, L, mass, U1, U2):
+        U1, U2 = _c128(U1), _c128(U2)
+        if U1.size != L * L or U2.size != L * L:
+            raise EngineError("link arrays must have L*L entries")
+        self._chk(self._lib.sw_set_lattice(self._h, hid, L, float(mass), _ptr(U1), _ptr(U2)),
+                  "sw_set_lattice")
+        self.level_sizes[hid][0] = 2 * L * L
+
+    def set_csr(self, hid, level, A):
+        (n, m), indptr, indices, data = _csr_parts(A)
+        if n != m:
+            raise EngineError("level operator must be square")
+        self._chk(self._lib.sw_set_csr(self._h, hid, level, n, _ptr(indptr), _ptr(indices),
+                                       _ptr(data)), "sw_set_csr")
+        self.level_sizes[hid][level] = n
+
+    def set_transfer(self, hid, level, P):
+        (nf, nc), indptr, indices, data = _csr_parts(P)
+        self._chk(self._lib.sw_set_transfer(self._h, hid, level, nf, nc, _ptr(indptr),
+                                            _ptr(indices), _ptr(data)), "sw_set_transfer")
+        self.level_sizes[hid][level] = nf
+        self.level_sizes[hid][level + 1] = nc
+
+    def set_coarsest_inv(self, hid, M):
+        M = _c128(np.asarray(M))
+        if M.ndim != 2 or M.shape[0] != M.shape[1]:
+            raise EngineError("coarsest inverse must be a square dense matrix")
+        self._chk(self._lib.sw_set_coarsest_inv(self._h, hid, M.shape[0], _ptr(M)),
+                  "sw_set_coarsest_inv")
+        self.level_sizes[hid][-1] = M.shape[0]
+
+    def set_cycle(self, hid, level, nu_pre, nu_post, kcycle=0):
+        self._chk(self._lib.sw_set_cycle(self._h, hid, level, nu_pre, nu_post, kcycle),
+                  "sw_set_cycle")
+
+    def hier_end(self, hid):
+        self._chk(self._lib.sw_hier_end(self._h, hid), "sw_hier_end")
+
+    def set_deflation(self, U):
+        if U is None:
+            self._chk(self._lib.sw_set_deflation(self._h, 0, None), "sw_set_deflation")
+            return
+        U = _c128(np.asarray(U))
+        self._chk(self._lib.sw_set_deflation(self._h, U.shape[1], _ptr(U)), "sw_set_deflation")
+
+    def set_perm(self, level, shift):
+        self._chk(self._lib.sw_set_perm(self._h, level, int(shift)), "sw_set_perm")
+
+    def set_rhsmap(self, level, Cmat):
+        (n, m), indptr, indices, data = _csr_parts(Cmat)
+        self._chk(self._lib.sw_set_rhsmap(self._h, level, n, _ptr(indptr), _ptr(indices),
+                                          _ptr(data)), "sw_set_rhsmap")
+
+    def set_solver(self, restart=24, solver_hid=0):
+        self._chk(self._lib.sw_set_solver(self._h, restart, solver_hid), "sw_set_solver")
+
+    # -- building blocks -------------------------------------------------------------------
+    def _io(self, X, n_in):
+        X = _c128(X)
+        single = X.ndim == 1
+        X2 = X.reshape(1, -1) if single else X
+        if X2.shape[1] != n_in:
+            raise EngineError("vector length %d, expected %d" % (X2.shape[1], n_in))
+        return X2, single
+
+    def _n(self, hid, level):
+        return self.level_sizes[hid][level]
+
+    def apply_dirac(self, hid, level, X):
+        X2, single = self._io(X, self._n(hid, level))
+        Y = np.empty_like(X2)
+        self._chk(self._lib.sw_apply_dirac(self._h, hid, level, X2.shape[0], _ptr(X2), _ptr(Y)),
+                  "sw_apply_dirac")
+        return Y[0] if single else Y
+
+    def restrict(self, hid, level, X):
+        X2, single = self._io(X, self._n(hid, level))
+        Y = np.empty((X2.shape[0], self._n(hid, level + 1)), dtype=np.complex128)
+        self._chk(self._lib.sw_restrict(self._h, hid, level, X2.shape[0], _ptr(X2), _ptr(Y)),
+                  "sw_restrict")
+        return Y[0] if single else Y
+
+    def prolong(self, hid, level, X):
+        X2, single = self._io(X, self._n(hid, level + 1))
+        Y = np.empty((X2.shape[0], self._n(hid, level)), dtype=np.complex128)
+        self._chk(self._lib.sw_prolong(self._h, hid, level, X2.shape[0], _ptr(X2), _ptr(Y)),
+                  "sw_prolong")
+        return Y[0] if single else Y
+
+    def coarsest(self, hid, X):
+        X2, single = self._io(X, self.level_sizes[hid][-1])
+        Y = np.empty_like(X2)
+        self._chk(self._lib.sw_coarsest(self._h, hid, X2.shape[0], _ptr(X2), _ptr(Y)),
+                  "sw_coarsest")
+        return Y[0] if single else Y
+
+    def vcycle(self, hid, level0, B):
+        B2, single = self._io(B, self._n(hid, level0))
+        X = np.empty_like(B2)
+        self._chk(self._lib.sw_vcycle(self._h, hid, level0, B2.shape[0], _ptr(B2), _ptr(X)),
+                  "sw_vcycle")
+        return X[0] if single else X
+
+    def solve(self, hid, level0, B, tol, maxiter=1000):
+        B2, single = self._io(B, self._n(hid, level0))
+        nb = B2.shape[0]
+        X = np.empty_like(B2)
+        iters = np.zeros(nb, dtype=np.int32)
+        relres = np.zeros(nb, dtype=np.float64)
+        self._chk(self._lib.sw_solve(self._h, hid, level0, nb, _ptr(B2), _ptr(X), float(tol),
+                                     int(maxiter), _ptr(iters), _ptr(relres)), "sw_solve")
+        if single:
+            return X[0], int(iters[0]), float(relres[0])
+        return X, iters, relres
+
+    # -- probe batches ---------------------------------------------------------------------
+    @staticmethod
+    def _probes(probes):
+        p = np.ascontiguousarray(probes, dtype=np.int8)
+        if p.ndim == 1:
+            p = p.reshape(1, -1)
+        return p
+
+    def hutch_batch(self, mode, level, probes, tol, maxiter=1000):
+        p = self._probes(probes)
+        nb = p.shape[0]
+        ests = np.zeros(nb, dtype=np.complex128)
+        iters = np.zeros(2 * nb, dtype=np.int32)
+        self._chk(self._lib.sw_hutch_batch(self._h, mode, level, nb, _ptr(p), float(tol),
+                                           int(maxiter), _ptr(ests), _ptr(iters)),
+                  "sw_hutch_batch")
+        return ests, iters[:nb].copy(), iters[nb:].copy()
+
+    def probes_upload(self, level, probes):
+        p = self._probes(probes)
+        self._nb_uploaded = p.shape[0]
+        self._chk(self._lib.sw_probes_upload(self._h, level, p.shape[0], _ptr(p)),
+                  "sw_probes_upload")
+
+    def hutch_run(self, mode, level, tol, maxiter=1000):
+        self._chk(self._lib.sw_hutch_run(self._h, mode, level, float(tol), int(maxiter)),
+                  "sw_hutch_run")
+
+    def sync(self):
+        self._chk(self._lib.sw_sync(self._h), "sw_sync")
+
+    def hutch_fetch(self):
+        nb = self._nb_uploaded
+        ests = np.zeros(nb, dtype=np.complex128)
+        iters = np.zeros(2 * nb, dtype=np.int32)
+        self._chk(self._lib.sw_hutch_fetch(self._h, _ptr(ests), _ptr(iters)), "sw_hutch_fetch")
+        return ests, iters[:nb].copy(), iters[nb:].copy()
+
+    # -- measurement -----------------------------------------------------------------------
+    def bench_dirac(self, hid, level, nb, reps):
+        ms = C.c_double(0.0)
+        self._chk(self._lib.sw_bench_dirac(self._h, hid, level, nb, reps, C.byref(ms)),
+                  "sw_bench_dirac")
+        return ms.value
+
+    def set_profiling(self, on):
+        self._chk(self._lib.sw_set_profiling(self._h, 1 if on else 0), "sw_set_profiling")
+
+    def timers(self):
+        t = (C.c_double * 8)()
+        self._chk(self._lib.sw_timers(self._h, t), "sw_timers")
+        return dict(zip(TIMER_NAMES, [float(v) for v in t]))
+
+    def timers_reset(self):
+        self._chk(self._lib.sw_timers_reset(self._h), "sw_timers_reset")
+
+    def launch_count(self):
+        n = C.c_int64(0)
+        self._chk(self._lib.sw_launch_count(self._h, C.byref(n)), "sw_launch_count")
+        return int(n.value)
+
+
+class ProbeStream:
+    """The reference's Rademacher stream (utils.py:213-216) without NumPy's global state:
+    MT19937 seeded as ``np.random.seed(seed)``; host-only, needs no GPU."""
+
+    def __init__(self, seed):
+        self._lib = load_library()
+        self._g = self._lib.sw_mt_create(int(seed) & 0xFFFFFFFF)
+        if not self._g:
+            raise EngineError("sw_mt_create failed")
+
+    def skip(self, ndraws):
+        self._lib.sw_mt_skip(self._g, int(ndraws))
+
+    def raw(self, n):
+        out = np.empty(int(n), dtype=np.uint32)
+        self._lib.sw_mt_raw(self._g, int(n), _ptr(out))
+        return out
+
+    def rademacher(self, count, n):
+        out = np.empty((int(count), int(n)), dtype=np.int8)
+        self._lib.sw_mt_rademacher(self._g, int(count) * int(n), _ptr(out))
+        return out
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._g:
+                self._lib.sw_mt_destroy(self._g)
+                self._g = None
+        except Exception:
+            pass

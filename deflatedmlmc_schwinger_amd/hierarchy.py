@@ -1,0 +1,294 @@
+"""Host-side construction of the operands the HIP engine consumes.
+
+Two hierarchies are built on the host (setup time, SciPy ARPACK + SuperLU as in the
+reference) and uploaded once:
+
+* the REFERENCE hierarchy -- index arithmetic of ``multigrid.py:100-345`` reproduced
+  exactly (strip aggregates of consecutive rows, even/odd "spin" split, single-pass
+  per-aggregate Gram-Schmidt, Galerkin coarse operators, Pperm / Bblock_perm
+  bookkeeping).  It defines the MLMC level operators, so it must match the reference;
+* an optional SOLVER hierarchy for level 0 -- 2-D site aggregates with a chirality
+  split, used only to precondition level-0 solves.  Converged solves do not depend on
+  the preconditioner, so this is free to differ from the reference.
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+# ---------------------------------------------------------------------------------------
+# lattice helpers
+# ---------------------------------------------------------------------------------------
+def links_from_matrix(S, L):
+    """U1(n) = -S[idx(0,n), idx(0,n+x)], U2(n) = -S[idx(0,n), idx(0,n+y)]."""
+    S = sp.csr_matrix(S)
+    site = np.arange(L * L)
+    x, y = site % L, site // L
+    right = y * L + (x + 1) % L
+    up = ((y + 1) % L) * L + x
+    U1 = -np.asarray(S[site, right]).ravel()
+    U2 = -np.asarray(S[site, up]).ravel()
+    return U1.astype(np.complex128), U2.astype(np.complex128)
+
+
+_HOP = {  # spin matrices of the four hops: (dx, dy, forward?) -> 2x2
+    "+x": np.array([[1, -1], [-1, 1]], dtype=np.complex128),
+    "-x": np.array([[1, 1], [1, 1]], dtype=np.complex128),
+    "+y": np.array([[1, 1j], [-1j, 1]], dtype=np.complex128),
+    "-y": np.array([[1, -1j], [1j, 1]], dtype=np.complex128),
+}
+
+
+def wilson_from_links(U1, U2, L):
+    """Explicit CSR of S (diagonal 4, no mass) from U(1) links, ordering idx(s,x,y)=s*L^2+y*L+x."""
+    V = L * L
+    site = np.arange(V)
+    x, y = site % L, site // L
+    nbr = {
+        "+x": (y * L + (x + 1) % L, U1),
+        "-x": (y * L + (x - 1) % L, None),
+        "+y": (((y + 1) % L) * L + x, U2),
+        "-y": (((y - 1) % L) * L + x, None),
+    }
+    nbr["-x"] = (nbr["-x"][0], np.conj(U1[nbr["-x"][0]]))
+    nbr["-y"] = (nbr["-y"][0], np.conj(U2[nbr["-y"][0]]))
+    ri, ci, vv = [], [], []
+    for a in range(2):
+        ri.append(a * V + site)
+        ci.append(a * V + site)
+        vv.append(np.full(V, 4.0, dtype=np.complex128))
+        for b in range(2):
+            for key, (dst, link) in nbr.items():
+                ri.append(a * V + site)
+                ci.append(b * V + dst)
+                vv.append(-_HOP[key][a, b] * link)
+    M = sp.coo_matrix((np.concatenate(vv), (np.concatenate(ri), np.concatenate(ci))),
+                      shape=(2 * V, 2 * V))
+    return sp.csr_matrix(M)
+
+
+def detect_lattice(A):
+    """If A = S + m*I for a U(1) Wilson stencil on an L x L torus, return (L, mass, U1, U2);
+    otherwise None.  The check is exact (entry-wise) so a positive answer means the matrix-free
+    stencil reproduces A bit for bit."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    if n % 2:
+        return None
+    L = int(round(np.sqrt(n // 2)))
+    if 2 * L * L != n or L < 4 or L % 2:
+        return None
+    d = A.diagonal()
+    if not np.all(d == d[0]) or d[0].imag != 0.0:
+        return None
+    mass = float(d[0].real) - 4.0
+    S = A - sp.identity(n, dtype=A.dtype, format="csr") * (mass)
+    U1, U2 = links_from_matrix(S, L)
+    if abs(np.abs(U1) - 1).max() > 1e-12 or abs(np.abs(U2) - 1).max() > 1e-12:
+        return None
+    S2 = wilson_from_links(U1, U2, L)
+    A2 = S2 + sp.identity(n, dtype=np.complex128, format="csr") * mass
+    diff = abs(A - A2)
+    if diff.nnz and diff.max() > 0.0:
+        return None
+    return L, mass, U1, U2
+
+
+# ---------------------------------------------------------------------------------------
+# reference hierarchy
+# ---------------------------------------------------------------------------------------
+class LevelML:
+    """Per-level container with the attribute names ``stoch_trace``/``utils`` read
+    (multigrid.py:26-37)."""
+    R = 0
+    P = 0
+    A = 0
+    Q = 0
+    Pperm = 0
+    perm_shift = 0
+    Bblock_perm = 0
+    g3 = 0
+
+
+class SimpleML:
+    def __init__(self):
+        self.levels = []
+
+    def __str__(self):
+        out = []
+        for idx, level in enumerate(self.levels[:-1]):
+            out.append("Level: %d" % idx)
+            out.append("\tsize(R) = " + str(level.R.shape))
+            out.append("\tsize(P) = " + str(level.P.shape))
+            out.append("\tsize(A) = " + str(level.A.shape))
+        return "\n".join(out)
+
+
+def shift_operator(n, shift):
+    """The matrix the reference stores as ``Pperm`` (multigrid.py:151-153): Pperm^T moves
+    entry i to i+shift (cyclic), i.e. (Pperm^T v)[i] = v[(i-shift) mod n]."""
+    cols = np.arange(n)
+    rows = (cols - shift) % n
+    # Pperm[r, c] = 1 with r = (c - shift) mod n  <=>  Pperm^T[c, r] = 1
+    return sp.csr_matrix((np.ones(n), (rows, cols)), shape=(n, n))
+
+
+def level_layout(i, dof, aggrs):
+    """Sizes used at level i of the reference setup (multigrid.py:123-127,192-199)."""
+    dofi = dof[i] if i == 0 else int(dof[i] / 2)
+    nvec = int(dof[i + 1] / 2)
+    aggr_size = aggrs[i] * dofi if i == 0 else aggrs[i] * dofi * 2
+    return dofi, nvec, aggr_size
+
+
+def prolongator_from_testvectors(tv, n, i, dof, aggrs):
+    """Block-column P of multigrid.py:192-262, vectorised over aggregates.
+
+    Row ``j*aggr_size + loc`` belongs to aggregate j; within the aggregate the position
+    ``loc % dofi`` decides the half: the first ``dofi/2`` positions of every group of
+    ``dofi`` rows feed columns ``[0, nvec)`` of the aggregate, the rest ``[nvec, 2 nvec)``.
+    Each half is orthonormalised with ONE classical Gram-Schmidt sweep (coefficients taken
+    against the not-yet-updated column), as the reference does."""
+    dofi, nvec, aggr_size = level_layout(i, dof, aggrs)
+    if n % aggr_size:
+        raise Exception("matrix size %d is not a multiple of the aggregate size %d" % (n, aggr_size))
+    na = n // aggr_size
+    hd = max(1, dofi // 2)
+    loc = np.arange(aggr_size)
+    upper = (loc % dofi) >= hd                       # True -> second ("spin 1") half
+    blocks = np.asarray(tv)[:, :nvec].reshape(na, aggr_size, nvec).astype(np.complex128)
+    halves = []
+    for mask in (~upper, upper):
+        Bh = blocks * mask[None, :, None]
+        for k in range(nvec):
+            if k:
+                coef = np.einsum("arw,ar->aw", Bh[:, :, :k].conj(), Bh[:, :, k])
+                Bh[:, :, k] -= np.einsum("arw,aw->ar", Bh[:, :, :k], coef)
+            nrm = np.sqrt(np.einsum("ar,ar->a", Bh[:, :, k].conj(), Bh[:, :, k]).real)
+            Bh[:, :, k] /= nrm[:, None]
+        halves.append(Bh)
+    full = np.concatenate(halves, axis=2)            # [na, aggr_size, 2 nvec]
+    rows = (np.arange(na)[:, None, None] * aggr_size + loc[None, :, None]
+            + np.zeros((1, 1, 2 * nvec), dtype=np.int64))
+    cols = (np.arange(na)[:, None, None] * (2 * nvec) + np.arange(2 * nvec)[None, None, :]
+            + np.zeros((1, aggr_size, 1), dtype=np.int64))
+    keep = np.concatenate([np.broadcast_to((~upper)[None, :, None], (na, aggr_size, nvec)),
+                           np.broadcast_to(upper[None, :, None], (na, aggr_size, nvec))], axis=2)
+    P = sp.csr_matrix((full[keep], (rows[keep], cols[keep])), shape=(n, na * 2 * nvec))
+    return P
+
+
+def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvectors=None):
+    """multigrid.py:100-345 -> (SimpleML, coarsest_inv, testvectors)."""
+    if params["test_vectors_type"] not in ("EVs",):
+        if params["test_vectors_type"] in ("LSVs", "RSVs"):
+            raise Exception("test vectors of type %s are not supported by this build "
+                            "(the shipped presets use 'EVs')" % params["test_vectors_type"])
+        raise Exception("unknown type of test vectors")
+    if acc_eigvs == "low":
+        tolx = 1.0e-3
+    elif acc_eigvs == "high":
+        tolx = 1.0e-9
+    else:
+        raise Exception("<accuracy_mg_eigvs> does not have a possible value.")
+    ml = SimpleML()
+    Al = sp.csr_matrix(A).astype(np.complex128)
+    lev = LevelML()
+    lev.A = Al.copy()
+    ml.levels.append(lev)
+    used = []
+    for i in range(max_levels - 1):
+        n = Al.shape[0]
+        nvec = int(dof[i + 1] / 2)
+        sign = np.ones(n)
+        sign[n // 2:] = -1.0
+        ml.levels[i].g3 = sp.diags([sign], [0])
+        if params["use_permuted"] and i == 0:
+            shift0 = params["latt_dims"][0] * 2 * params["x_displacement"]
+            ml.levels[0].perm_shift = shift0
+            ml.levels[0].Pperm = shift_operator(n, shift0)
+            ml.levels[0].Bblock_perm = sp.identity(n, dtype=np.complex128, format="csr")
+        if testvectors is not None:
+            tv = np.asarray(testvectors[i])
+        else:
+            ncv = nvec + 2 if acc_eigvs == "low" else None
+            _, tv = spla.eigs(sp.csc_matrix(Al), k=nvec, which="LM", tol=tolx, maxiter=1000000,
+                              sigma=0.0, ncv=ncv)
+        used.append(tv)
+        Pl = prolongator_from_testvectors(tv, n, i, dof, aggrs)
+        Rl = sp.csr_matrix(Pl.conjugate().transpose())
+        ml.levels[i].P = Pl
+        ml.levels[i].R = Rl
+        Al = sp.csr_matrix(Rl @ Al @ Pl)
+        nxt = LevelML()
+        nxt.A = Al.copy()
+        ml.levels.append(nxt)
+        if params["use_permuted"]:
+            sh = int((ml.levels[i].perm_shift / (dof[i] * aggrs[i])) * dof[i + 1])
+            nxt.perm_shift = sh
+            nxt.Pperm = shift_operator(Pl.shape[1], sh)
+            Bl = ml.levels[i].Pperm.transpose().conjugate() @ (Pl @ nxt.Pperm)
+            nxt.Bblock_perm = sp.csr_matrix((Rl @ ml.levels[i].Bblock_perm) @ Bl)
+    coarsest_inv = np.matrix(np.linalg.inv(ml.levels[-1].A.toarray()))
+    return ml, coarsest_inv, used
+
+
+# ---------------------------------------------------------------------------------------
+# solver hierarchy (level-0 preconditioner only)
+# ---------------------------------------------------------------------------------------
+DEFAULT_SOLVER_CFG = {
+    # (aggregate edge in sites of the level above, test vectors per chirality) per coarsening
+    "coarsening": [(4, 8), (4, 8)],
+    # per level: (nu_pre, nu_post, kcycle)
+    "cycle": [(0, 3, 2), (0, 3, 0)],
+    "restart": 24,
+    "eig_tol": 1.0e-6,
+}
+
+
+def _site_prolongator(Al, Lf, hd, agg, nvec, tv):
+    """P for 2-D aggregates: rows ordered [half][y][x][k<hd] on an Lf x Lf lattice, columns
+    ordered [half][yc][xc][v<nvec]; each (aggregate, half) block is orthonormalised by QR."""
+    n = Al.shape[0]
+    Lc = Lf // agg
+    idx = np.arange(n)
+    half = idx // (n // 2)
+    rem = idx % (n // 2)
+    site = rem // hd
+    x, y = site % Lf, site // Lf
+    block = half * (Lc * Lc) + (y // agg) * Lc + (x // agg)
+    order = np.argsort(block, kind="stable")
+    rows_per_block = n // (2 * Lc * Lc)
+    rows_sorted = order.reshape(2 * Lc * Lc, rows_per_block)
+    M = np.asarray(tv)[rows_sorted, :nvec]            # [blocks, rows, nvec]
+    Q, _ = np.linalg.qr(M)
+    rr = np.repeat(rows_sorted[:, :, None], nvec, axis=2)
+    cc = (np.arange(2 * Lc * Lc)[:, None, None] * nvec + np.arange(nvec)[None, None, :]
+          + np.zeros((1, rows_per_block, 1), dtype=np.int64))
+    return sp.csr_matrix((Q.ravel(), (rr.ravel(), cc.ravel())), shape=(n, 2 * Lc * Lc * nvec))
+
+
+def solver_hierarchy(A0, L, cfg=None, testvectors=None):
+    """Level-0 preconditioner hierarchy: returns dict(A=[...], P=[...], coarsest_inv, tv)."""
+    cfg = dict(DEFAULT_SOLVER_CFG if cfg is None else cfg)
+    As = [sp.csr_matrix(A0).astype(np.complex128)]
+    Ps = []
+    tvs = []
+    Lf, hd = L, 1
+    for lvl, (agg, nvec) in enumerate(cfg["coarsening"]):
+        if Lf % agg:
+            raise Exception("lattice extent %d not divisible by aggregate edge %d" % (Lf, agg))
+        if testvectors is not None:
+            tv = testvectors[lvl]
+        else:
+            _, tv = spla.eigs(sp.csc_matrix(As[-1]), k=nvec, which="LM", sigma=0.0,
+                              tol=cfg.get("eig_tol", 1e-6))
+        tvs.append(tv)
+        P = _site_prolongator(As[-1], Lf, hd, agg, nvec, tv)
+        Ac = sp.csr_matrix(P.conjugate().transpose() @ As[-1] @ P)
+        Ps.append(P)
+        As.append(Ac)
+        Lf //= agg
+        hd = nvec
+    cinv = np.linalg.inv(As[-1].toarray())
+    return {"A": As, "P": Ps, "coarsest_inv": cinv, "tv": tvs, "cfg": cfg}

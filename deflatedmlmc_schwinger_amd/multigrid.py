@@ -1,0 +1,252 @@
+"""``multigrid.MG`` of the reference (multigrid.py:56-557) on the MI355X engine.
+
+Same class name, constructor, method names and attributes; the arithmetic
+behind ``matvec`` / ``one_mg_step`` / ``solve`` / ``diff_op`` runs in the HIP library through
+:mod:`deflatedmlmc_schwinger_amd.engine`.  Setup (ARPACK test vectors, Galerkin products,
+dense inverse) stays on the host exactly as in the reference and is uploaded once.
+"""
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import hierarchy as _hier
+from .engine import Engine, EngineError
+from .hierarchy import LevelML, SimpleML  # noqa: F401  (re-exported, multigrid.py:26-48)
+from .utils import CustomTimer
+
+REF_HID = 0      # reference hierarchy (MLMC level operators)
+SOLVER_HID = 1   # level-0 preconditioner hierarchy
+
+
+class MG:
+
+    def __init__(self, A, smooth_iters=2):
+        # level from which solves start (changes during MLMC)            multigrid.py:59-61
+        self.level_nr = 0
+        self.ml = []
+        self.A = A
+        self.x = []
+        self.num_iters = 0
+        self.total_levels = 0
+        self.coarsest_iters = 0
+        self.coarsest_iters_tot = 0
+        self.coarsest_iters_avg = 0
+        self.nr_calls = 0
+        self.smooth_iters = smooth_iters
+        self.coarsest_lev_iters = [0] * 10
+        self.level_for_diff_op = 0
+        self.solve_tol = 1.0e-1
+        self.coarsest_inv = []
+        self.timer = CustomTimer()
+        self.skip_level = False
+        # build-specific state
+        self.engine = None
+        self.device = 0
+        self.solver_info = None
+        self.testvectors = None
+        self._A0 = A
+        self._have_solver_hier = False
+        self.maxiter_cap = 1000
+
+    # ------------------------------------------------------------------------------------
+    def setup(self, dof=[2, 8, 8], aggrs=[2 * 2, 2 * 2], max_levels=3, dim=2, acc_eigvs='low',
+              sys_type='schwinger', params=None):
+        """Host setup as multigrid.py:100-345, then upload to the GPU engine."""
+        if params is None:
+            raise Exception("setup needs the trace parameter dictionary")
+        tv = params.get("mg_testvectors")
+        ml, cinv, used = _hier.reference_hierarchy(self._A0, dof, aggrs, max_levels, acc_eigvs,
+                                                   params, testvectors=tv)
+        self.ml = ml
+        self.coarsest_inv = cinv
+        self.testvectors = used
+        self.total_levels = len(ml.levels)
+        self.A = ml.levels[0].A
+        self._upload(params)
+
+    def attach_hierarchy(self, ml, coarsest_inv, params):
+        """Use an already built reference hierarchy (e.g. from a cache) instead of setup()."""
+        self.ml = ml
+        self.coarsest_inv = coarsest_inv
+        self.total_levels = len(ml.levels)
+        self.A = ml.levels[0].A
+        self._upload(params)
+
+    def _upload(self, params):
+        device = int(params.get("device", self.device)) if params else self.device
+        if self.engine is None:
+            self.engine = Engine(device)
+        eng = self.engine
+        levels = self.ml.levels
+        nlev = len(levels)
+        lat = _hier.detect_lattice(levels[0].A)
+        self.lattice = lat
+        eng.hier_begin(REF_HID, nlev)
+        if lat is not None:
+            L, mass, U1, U2 = lat
+            eng.set_lattice(REF_HID, L, mass, U1, U2)
+        else:
+            eng.set_csr(REF_HID, 0, levels[0].A)
+        for i in range(nlev - 1):
+            if i > 0:
+                eng.set_csr(REF_HID, i, levels[i].A)
+            eng.set_transfer(REF_HID, i, levels[i].P)
+            # MR(nu) stands in for lgmres(maxiter=smooth_iters); see DESIGN.md section 4
+            eng.set_cycle(REF_HID, i, 0, int(params.get("ref_cycle_post", 4)) if params else 4,
+                          int(params.get("ref_cycle_k", 0)) if params else 0)
+        eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A) if nlev > 1 else None
+        eng.set_coarsest_inv(REF_HID, np.asarray(self.coarsest_inv))
+        eng.hier_end(REF_HID)
+        for i in range(nlev):
+            if params and params.get("use_permuted") and not isinstance(levels[i].Pperm, int):
+                eng.set_perm(i, int(levels[i].perm_shift))
+                Cmat = levels[i].Bblock_perm @ levels[i].Pperm.transpose()
+                eng.set_rhsmap(i, sp.csr_matrix(Cmat))
+        # level-0 preconditioner
+        cfg = params.get("solver_cfg") if params else None
+        want = True if params is None else params.get("use_solver_hierarchy", True)
+        self._have_solver_hier = False
+        restart = 24
+        if want and lat is not None:
+            cfg = dict(_hier.DEFAULT_SOLVER_CFG if cfg is None else cfg)
+            L = lat[0]
+            ok = True
+            Lf = L
+            for (agg, _) in cfg["coarsening"]:
+                ok = ok and (Lf % agg == 0) and (Lf // agg >= 1)
+                Lf //= max(agg, 1)
+            if ok:
+                t0 = time.time()
+                sh = _hier.solver_hierarchy(levels[0].A, L, cfg,
+                                            testvectors=params.get("solver_testvectors"))
+                nl = len(sh["A"])
+                eng.hier_begin(SOLVER_HID, nl)
+                eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
+                for i in range(nl - 1):
+                    if i > 0:
+                        eng.set_csr(SOLVER_HID, i, sh["A"][i])
+                    eng.set_transfer(SOLVER_HID, i, sh["P"][i])
+                    cyc = cfg["cycle"][i]
+                    eng.set_cycle(SOLVER_HID, i, cyc[0], cyc[1], cyc[2])
+                eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
+                eng.hier_end(SOLVER_HID)
+                self._have_solver_hier = True
+                self.solver_info = {"levels": [a.shape[0] for a in sh["A"]],
+                                    "setup_s": time.time() - t0, "cfg": cfg}
+                restart = int(cfg.get("restart", 24))
+        eng.set_solver(restart, SOLVER_HID if self._have_solver_hier else REF_HID)
+
+    # ------------------------------------------------------------------------------------
+    def _need_engine(self):
+        if self.engine is None:
+            raise EngineError("MG.setup() has not been run: no GPU engine attached")
+        return self.engine
+
+    def _level_of(self, A):
+        for i, lev in enumerate(self.ml.levels):
+            if lev.A is A:
+                return i
+        for i, lev in enumerate(self.ml.levels):
+            if lev.A.shape == A.shape:
+                return i
+        raise Exception("matrix does not belong to the multigrid hierarchy")
+
+    def _hid_for(self, level):
+        return SOLVER_HID if (level == 0 and self._have_solver_hier) else REF_HID
+
+    def solve(self, A, b, tol):
+        """multigrid.py:347-366: result in self.x, iteration count in self.num_iters."""
+        eng = self._need_engine()
+        n = A.shape[0]
+        maxiter = n if n < 1000 else self.maxiter_cap
+        lvl = self.level_nr
+        self.A = self.ml.levels[lvl].A
+        x, its, _ = eng.solve(self._hid_for(lvl), lvl, np.asarray(b).reshape(-1), tol, maxiter)
+        self.x = x
+        self.num_iters = its
+
+    def solve_batch(self, level, B, tol, maxiter=None):
+        """Multi-RHS form of solve(): B has one right-hand side per row."""
+        eng = self._need_engine()
+        n = self.ml.levels[level].A.shape[0]
+        if maxiter is None:
+            maxiter = n if n < 1000 else self.maxiter_cap
+        return eng.solve(self._hid_for(level), level, B, tol, maxiter)
+
+    def one_mg_step(self, b):
+        """multigrid.py:369-447: one cycle starting at self.level_nr."""
+        eng = self._need_engine()
+        lvl = self.level_nr
+        nlev = len(self.ml.levels)
+        self.coarsest_lev_iters[lvl] += 1
+        self.coarsest_iters = 1
+        self.nr_calls += 1
+        self.coarsest_iters_tot += 1
+        self.coarsest_iters_avg = self.coarsest_iters_tot / self.nr_calls
+        if lvl == nlev - 1:
+            return eng.coarsest(REF_HID, np.asarray(b).reshape(-1))
+        return eng.vcycle(self._hid_for(lvl), lvl, np.asarray(b).reshape(-1))
+
+    def matvec(self, x):
+        """multigrid.py:552-557: y = self.A * x on the GPU."""
+        eng = self._need_engine()
+        lvl = self._level_of(self.A)
+        return eng.apply_dirac(REF_HID, lvl, np.asarray(x).reshape(-1))
+
+    def __str__(self):
+        out = "\nMultilevel information:\n"
+        last = len(self.ml.levels) - 1
+        for idx, level in enumerate(self.ml.levels):
+            out += "Level: " + str(idx) + "\n"
+            if idx < last:
+                out += "\tsize(R) = " + str(level.R.shape) + "\n"
+                out += "\tsize(P) = " + str(level.P.shape) + "\n"
+            out += "\tsize(A) = " + str(level.A.shape) + "\n"
+        return out
+
+    # ------------------------------------------------------------------------------------
+    def diff_op_Q(self, v):
+        """multigrid.py:461-468.  Like the reference, the sign flip is applied IN PLACE to
+        the caller's array (``vx = v[:]`` is a view there)."""
+        half = int(v.shape[0] / 2)
+        v[half:] = -v[half:]
+        return self.diff_op(v)
+
+    def diff_op(self, v):
+        """multigrid.py:471-549: (A_f^-1 - P A_c^-1 R) v at self.level_for_diff_op."""
+        eng = self._need_engine()
+        lvl = self.level_for_diff_op
+        nlev = len(self.ml.levels)
+        skip = self.skip_level and lvl == 0
+        v = np.asarray(v, dtype=np.complex128).reshape(-1)
+        vc = eng.restrict(REF_HID, lvl, v)
+        lc = lvl + 1
+        if skip:
+            vc = eng.restrict(REF_HID, lvl + 1, vc)
+            lc = lvl + 2
+        self.level_nr = lvl
+        self.solve(self.ml.levels[lvl].A, v, self.solve_tol)
+        t1 = self.x
+        if lc == nlev - 1:
+            t2 = eng.coarsest(REF_HID, vc)
+        else:
+            self.level_nr = lc
+            self.solve(self.ml.levels[lc].A, vc, self.solve_tol)
+            t2 = self.x
+        if skip:
+            t2 = eng.prolong(REF_HID, lvl + 1, t2)
+        return t1 - eng.prolong(REF_HID, lvl, t2)
+
+    # ------------------------------------------------------------------------------------
+    def sync_timer(self):
+        """Copy the engine's HIP-event buckets (ms) into the CustomTimer fields (s)."""
+        if self.engine is None:
+            return
+        t = self.engine.timers()
+        self.timer.mvm = (t["mvm"] + t["coarsest"]) * 1e-3
+        self.timer.defl = t["defl"] * 1e-3
+        self.timer.P = t["P"] * 1e-3
+        self.timer.R = t["R"] * 1e-3
+        self.timer.axpy = t["axpy"] * 1e-3
+        self.timer.dots = t["dots"] * 1e-3

@@ -1,0 +1,144 @@
+/*
+ * schwinger_hip.h -- C ABI of the MI355X (gfx950) deflated-MLMC Hutchinson trace engine.
+ *
+ * This is the drop-in boundary for the hot path of Gustavroot/DeflatedMLMC_Schwinger
+ * (SURVEY.md section 8).  The reference has no native code: every arithmetic call on the
+ * path goes through SciPy/NumPy/pyamg wheels.  Each entry point below names the
+ * reference call site(s) (file:line under the reference repo) whose work it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; sw_last_error() gives text;
+ *     no C++ exception crosses the boundary;
+ *   - complex numbers are interleaved (re, im) doubles ("complex128"); `double*` arguments
+ *     that hold complex data say so;
+ *   - host vectors use the REFERENCE ordering and shape: `nb` right-hand sides, each a
+ *     contiguous flat vector of length n (level 0: idx(s,x,y) = s*L*L + y*L + x);
+ *   - all buffers are caller-owned host memory unless the name ends in _dev;
+ *   - one host thread per handle; device streams are internal;
+ *   - a handle holds up to SW_MAX_HIER multigrid hierarchies (`hid`): hid 0 is the
+ *     reference hierarchy (the MLMC level operators of multigrid.py:100-345), hid 1 an
+ *     optional solver-only hierarchy for level 0 (parity is on converged solves).
+ */
+#ifndef SCHWINGER_HIP_H
+#define SCHWINGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_MAX_HIER 2
+#define SW_MAX_LEVELS 8
+#define SW_MAX_KRYLOV 48
+#define SW_MAX_DEFL 64
+
+typedef struct sw_engine sw_engine;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* Replaces MG.__init__ (multigrid.py:58-89).  Fails (non-zero) when no HIP device exists. */
+int sw_create(sw_engine** out, int device_id);
+int sw_destroy(sw_engine* h);
+const char* sw_last_error(sw_engine* h);          /* h may be NULL: last create() error */
+int sw_device_count(void);                         /* 0 when no GPU is visible            */
+const char* sw_version(void);
+
+/* ---- operands (products of MG.setup, multigrid.py:100-345, and matrix.py:14-31) ------ */
+/* Start (or reset) hierarchy `hid` with `nlevels` levels. */
+int sw_hier_begin(sw_engine* h, int hid, int nlevels);
+/* Level-0 operator as the matrix-free U(1) Wilson stencil A = S + mass*I of SURVEY F2
+ * (replaces the CSR built by matrix.py:21-29).  U1,U2: complex128[L*L], site index y*L+x.
+ * Sets n_0 = 2*L*L and the even-odd internal layout. */
+int sw_set_lattice(sw_engine* h, int hid, int L, double mass, const double* U1, const double* U2);
+/* Level operator as CSR, complex128 data (multigrid.py:276-280 A_{l+1} = R A P; also
+ * accepted for level 0 when no lattice is set). */
+int sw_set_csr(sw_engine* h, int hid, int level, int n, const int64_t* indptr,
+               const int32_t* indices, const double* data);
+/* Prolongator P_l (n_f x n_c CSR, multigrid.py:262-264); R_l = P_l^H (multigrid.py:267-274). */
+int sw_set_transfer(sw_engine* h, int hid, int level, int n_f, int n_c, const int64_t* indptr,
+                    const int32_t* indices, const double* data);
+/* Dense inverse of the coarsest operator, row-major complex128[n*n] (multigrid.py:342-344). */
+int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense);
+/* Cycle shape at `level`: MR smoothing steps before/after the coarse correction and the
+ * number of flexible-GMRES steps wrapped around the next-level cycle (0 = plain V-cycle).
+ * Stands in for lgmres(maxiter=smooth_iters) at multigrid.py:393-394,438-439 (parity is on
+ * converged solves). */
+int sw_set_cycle(sw_engine* h, int hid, int level, int nu_pre, int nu_post, int kcycle);
+/* Mark the hierarchy complete (allocates level workspaces lazily). */
+int sw_hier_end(sw_engine* h, int hid);
+
+/* Deflation vectors U (utils.py:145-155), row-major complex128[n0*k], reference ordering. */
+int sw_set_deflation(sw_engine* h, int k, const double* U);
+/* Index shift of Pperm at `level` of hid 0 (multigrid.py:142-155,320-326). shift<0 clears. */
+int sw_set_perm(sw_engine* h, int level, int64_t shift);
+/* MLMC right-hand-side map C_i = Bblock_perm_i * Pperm_i^T as CSR (multigrid.py:328-331,
+ * utils.py:288-290); n x n at `level` of hid 0. */
+int sw_set_rhsmap(sw_engine* h, int level, int n, const int64_t* indptr, const int32_t* indices,
+                  const double* data);
+/* Outer flexible-GMRES restart length (<= SW_MAX_KRYLOV) and the hierarchy used to
+ * precondition level-0 solves (0 or 1). */
+int sw_set_solver(sw_engine* h, int restart, int solver_hid);
+
+/* ---- building blocks (host buffers, reference ordering) -------------------------------- */
+/* Y = A_level X.  Replaces MG.matvec (multigrid.py:552-557) and the residual SpMVs at
+ * multigrid.py:388,402,433.  X,Y: complex128[nb*n]. */
+int sw_apply_dirac(sw_engine* h, int hid, int level, int nb, const double* X, double* Y);
+/* Y = R_level X (multigrid.py:406; utils.py:301-303) / Y = P_level X (multigrid.py:429;
+ * utils.py:339-341). */
+int sw_restrict(sw_engine* h, int hid, int level, int nb, const double* X, double* Y);
+int sw_prolong(sw_engine* h, int hid, int level, int nb, const double* X, double* Y);
+/* Y = coarsest_inv X (multigrid.py:413-416; utils.py:309-310,321-322). */
+int sw_coarsest(sw_engine* h, int hid, int nb, const double* X, double* Y);
+/* X = one multigrid cycle applied to B starting at level0 (MG.one_mg_step, multigrid.py:369-447). */
+int sw_vcycle(sw_engine* h, int hid, int level0, int nb, const double* B, double* X);
+/* Solve A_level0 X = B to ||r|| < tol*||b|| per right-hand side (MG.solve -> pyamg fgmres,
+ * multigrid.py:347-366).  iters[nb], relres[nb] may be NULL.  Non-convergence within
+ * maxiter is NOT an error (the reference discards exitCode); it is visible in relres. */
+int sw_solve(sw_engine* h, int hid, int level0, int nb, const double* B, double* X, double tol,
+             int maxiter, int32_t* iters, double* relres);
+
+/* ---- the probe loop body ----------------------------------------------------------------- */
+#define SW_MODE_HUTCHINSON 0   /* utils.py:210-250 */
+#define SW_MODE_MLMC 1         /* utils.py:252-361 */
+#define SW_MODE_MLMC_SKIP 2    /* utils.py:252-361 with mg_solver.skip_level and i == 0 */
+/* One batch of probes x_k in {-1,+1}^n (int8, nb*n, reference ordering) at `level`:
+ *   HUTCHINSON: e_k = x^H A^-1 Pperm^T (x - U U^H x)
+ *   MLMC:       e_k = x^H A_f^-1 C x - x^H P A_c^-1 R C x   (SKIP: P0 P1, R1 R0)
+ * ests: complex128[nb]; iters: int32[2*nb] = fine-solve and coarse-solve iteration counts. */
+int sw_hutch_batch(sw_engine* h, int mode, int level, int nb, const int8_t* probes, double tol,
+                   int maxiter, double* ests, int32_t* iters);
+/* Split form used when the probes are to be resident in HBM before timing starts:
+ * upload -> run (asynchronous on the engine stream) -> sync -> fetch. */
+int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes);
+int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter);
+int sw_sync(sw_engine* h);
+int sw_hutch_fetch(sw_engine* h, double* ests, int32_t* iters);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+/* Timed stencil loop for the roofline figure: `reps` applications of the level-0 operator of
+ * hierarchy hid on nb resident right-hand sides, HIP events on the engine stream.
+ * ms_per_apply is the average launch duration. */
+int sw_bench_dirac(sw_engine* h, int hid, int level, int nb, int reps, double* ms_per_apply);
+/* Bucketed device time (ms) since the last reset, measured with HIP events when profiling
+ * is enabled (CustomTimer buckets of utils.py:366-445 plus the Krylov BLAS-1 the reference
+ * leaves untimed):  [0]=mvm [1]=defl [2]=P [3]=R [4]=axpy [5]=dots [6]=coarsest [7]=other. */
+int sw_set_profiling(sw_engine* h, int on);
+int sw_timers(sw_engine* h, double t[8]);
+int sw_timers_reset(sw_engine* h);
+/* Kernel launches issued since the last reset (for launch-bound analysis). */
+int sw_launch_count(sw_engine* h, int64_t* n);
+
+/* ---- host-only helpers (no GPU needed) ---------------------------------------------------- */
+/* The probe stream of utils.py:213-216: MT19937 seeded as np.random.seed(seed); entry =
+ * 2*(next_uint32 & 1) - 1; the stream continues across calls. */
+typedef struct sw_mt19937 sw_mt19937;
+sw_mt19937* sw_mt_create(uint32_t seed);
+void sw_mt_destroy(sw_mt19937* g);
+void sw_mt_skip(sw_mt19937* g, uint64_t ndraws);
+void sw_mt_raw(sw_mt19937* g, uint64_t n, uint32_t* out);
+void sw_mt_rademacher(sw_mt19937* g, uint64_t n, int8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCHWINGER_HIP_H */

@@ -1,0 +1,74 @@
+"""NumPy model of the ENGINE's own multigrid cycle (MR(nu)-smoothed V/K-cycle, batched
+flexible GMRES).  TEST INFRASTRUCTURE ONLY: it lets the GPU tests compare the HIP cycle
+against an independent CPU evaluation of the same formulae on the same operands.  The
+algorithm itself is the build's, not the reference's; the reference's
+cycle (lgmres smoother) lives in oracle/ref_path.py."""
+import numpy as np
+
+
+def cdot(X, Y):
+    return np.einsum("ij,ij->j", X.conj(), Y)
+
+
+def mr_smooth(A, X, R, nu):
+    for _ in range(nu):
+        T = A @ R
+        num = cdot(T, R)
+        den = cdot(T, T).real
+        alpha = np.where(den > 0, num / np.where(den > 0, den, 1.0), 0.0)
+        X = X + R * alpha
+        R = R - T * alpha
+    return X, R
+
+
+def fgmres_fixed(A, B, M, k):
+    """k steps of right-preconditioned flexible GMRES from a zero guess, per column."""
+    n, nb = B.shape
+    beta = np.sqrt(cdot(B, B).real)
+    V = [B * np.where(beta > 0, 1.0 / np.where(beta > 0, beta, 1.0), 0.0)]
+    Z = []
+    H = np.zeros((k + 1, k, nb), dtype=complex)
+    for j in range(k):
+        Zj = M(V[j])
+        W = A @ Zj
+        Z.append(Zj)
+        for _ in range(2):
+            for i in range(j + 1):
+                h = cdot(V[i], W)
+                H[i, j] += h
+                W = W - V[i] * h
+        hn = np.sqrt(cdot(W, W).real)
+        H[j + 1, j] = hn
+        V.append(W * np.where(hn > 0, 1.0 / np.where(hn > 0, hn, 1.0), 0.0))
+    X = np.zeros_like(B)
+    for c in range(nb):
+        e1 = np.zeros(k + 1, dtype=complex)
+        e1[0] = beta[c]
+        y = np.linalg.lstsq(H[:, :, c], e1, rcond=None)[0]
+        for i in range(k):
+            X[:, c] += y[i] * Z[i][:, c]
+    return X
+
+
+def cycle(As, Ps, cinv, cfg, level, B):
+    """cfg[l] = (nu_pre, nu_post, kcycle); B is [n, nb]."""
+    last = len(As) - 1
+    if level == last:
+        return np.asarray(cinv) @ B
+    nu_pre, nu_post, kc = cfg[level]
+    A, P = As[level], Ps[level]
+    R = P.conj().T
+    if nu_pre > 0:
+        X, res = mr_smooth(A, np.zeros_like(B), B.copy(), nu_pre)
+        Bc = R @ res
+    else:
+        X = None
+        Bc = R @ B
+    if kc > 0 and level + 1 < last:
+        Xc = fgmres_fixed(As[level + 1], Bc, lambda v: cycle(As, Ps, cinv, cfg, level + 1, v), kc)
+    else:
+        Xc = cycle(As, Ps, cinv, cfg, level + 1, Bc)
+    X = P @ Xc if X is None else X + P @ Xc
+    if nu_post > 0:
+        X, _ = mr_smooth(A, X, B - A @ X, nu_post)
+    return X

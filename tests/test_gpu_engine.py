@@ -1,0 +1,253 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): every C-ABI entry point of the hot
+path against the CPU oracle on the same seeded inputs.
+
+Tolerances: the path is complex128 floating point.  Single operator applications are compared
+at 1e-13 relative (different summation order than CSR), per-probe estimates at the north-star
+tolerance of 1e-10 relative against the sparse-LU oracle."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+from deflatedmlmc_schwinger_amd import gateway, matrix, utils  # noqa: E402
+from deflatedmlmc_schwinger_amd.engine import (MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP)  # noqa: E402
+from deflatedmlmc_schwinger_amd.multigrid import MG, REF_HID, SOLVER_HID  # noqa: E402
+from oracle import engine_model as em  # noqa: E402
+from oracle import ref_path as rp  # noqa: E402
+
+
+def _rand(shape, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+def _relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+class Problem:
+    def __init__(self, name, k_defl, batch_solver_cfg=None):
+        params = gateway.set_params(name)
+        params['function_tol'] = 1e-12
+        self.params = params
+        self.A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+        self.tp = utils.trace_params_from_params(params, "mlmc")
+        self.tp['nr_deflat_vctrs'] = k_defl
+        self.tp['mlmc_deflat_vctrs'] = [0] * 3
+        self.mg = MG(self.A)
+        self.mg.setup(dof=self.tp['dof'], aggrs=self.tp['aggrs'],
+                      max_levels=self.tp['max_nr_levels'], dim=2,
+                      acc_eigvs=self.tp['accuracy_mg_eigvs'], sys_type='schwinger', params=self.tp)
+        self.mg.total_levels = len(self.mg.ml.levels)
+        self.Ux, self.tr1 = utils.deflation_pre_computations(
+            self.A, k_defl, 1e-9, "hutchinson", self.mg.timer, self.tp, self.mg)
+        self.levels = self.mg.ml.levels
+        self.eng = self.mg.engine
+        self.lu = {}
+
+    def lu_solver(self, level):
+        if level not in self.lu:
+            self.lu[level] = rp.LUSolver(self.levels[level].A)
+        return self.lu[level]
+
+
+@pytest.fixture(scope="module")
+def p16():
+    return Problem('schwinger16', 8)
+
+
+@pytest.fixture(scope="module")
+def p128():
+    return Problem('schwinger128', 8)
+
+
+@pytest.mark.parametrize("nb", [1, 3, 70])
+def test_dirac_stencil_matches_csr_16(p16, nb):
+    X = _rand((nb, p16.A.shape[0]), 1)
+    Y = p16.eng.apply_dirac(REF_HID, 0, X)
+    ref = (p16.A @ X.T).T
+    assert _relerr(Y, ref) < 1e-13
+
+
+def test_dirac_stencil_matches_csr_128(p128):
+    X = _rand((5, p128.A.shape[0]), 2)
+    Y = p128.eng.apply_dirac(REF_HID, 0, X)
+    ref = (p128.A @ X.T).T
+    assert _relerr(Y, ref) < 1e-13
+    # same operator registered in the solver hierarchy
+    Y2 = p128.eng.apply_dirac(SOLVER_HID, 0, X)
+    assert np.array_equal(Y, Y2)
+
+
+def test_dirac_linearity_full_batch(p128):
+    """size-independent property at the benchmark batch size (nb = 256): A(aX+Y) = aAX+AY."""
+    n = p128.A.shape[0]
+    X, Y = _rand((256, n), 3), _rand((256, n), 4)
+    a = 0.7 - 0.3j
+    lhs = p128.eng.apply_dirac(REF_HID, 0, a * X + Y)
+    rhs = a * p128.eng.apply_dirac(REF_HID, 0, X) + p128.eng.apply_dirac(REF_HID, 0, Y)
+    assert _relerr(lhs, rhs) < 1e-13
+    # and one column against the CSR matrix
+    assert _relerr(lhs[17], p128.A @ (a * X[17] + Y[17])) < 1e-13
+
+
+@pytest.mark.parametrize("prob", ["p16", "p128"])
+def test_coarse_operators_and_transfers(prob, request):
+    p = request.getfixturevalue(prob)
+    nlev = len(p.levels)
+    for l in range(nlev):
+        n = p.levels[l].A.shape[0]
+        X = _rand((3, n), 10 + l)
+        Y = p.eng.apply_dirac(REF_HID, l, X)
+        assert _relerr(Y, (p.levels[l].A @ X.T).T) < 1e-13, "A level %d" % l
+        if l < nlev - 1:
+            Yr = p.eng.restrict(REF_HID, l, X)
+            assert _relerr(Yr, (p.levels[l].R @ X.T).T) < 1e-13, "R level %d" % l
+            Xc = _rand((3, p.levels[l + 1].A.shape[0]), 20 + l)
+            Yp = p.eng.prolong(REF_HID, l, Xc)
+            assert _relerr(Yp, (p.levels[l].P @ Xc.T).T) < 1e-13, "P level %d" % l
+    Xc = _rand((4, p.levels[-1].A.shape[0]), 30)
+    Yc = p.eng.coarsest(REF_HID, Xc)
+    assert _relerr(Yc, (np.asarray(p.mg.coarsest_inv) @ Xc.T).T) < 1e-12
+
+
+def test_vcycle_matches_numpy_model(p16, p128):
+    for p in (p16, p128):
+        As = [l.A for l in p.levels]
+        Ps = [l.P for l in p.levels[:-1]]
+        post = 4
+        cfg = [(0, post, 0)] * (len(As) - 1)
+        for level0 in range(len(As) - 1):
+            B = _rand((As[level0].shape[0], 3), 40 + level0)
+            ref = em.cycle(As, Ps, p.mg.coarsest_inv, cfg, level0, B)
+            X = p.eng.vcycle(REF_HID, level0, B.T.copy())
+            assert _relerr(X.T, ref) < 1e-10, "cycle from level %d" % level0
+
+
+def test_solve_reaches_tolerance_and_matches_lu(p16, p128):
+    for p, tol_x in ((p16, 1e-9), (p128, 1e-8)):
+        n = p.A.shape[0]
+        B = _rand((6, n), 50)
+        X, iters, relres = p.mg.solve_batch(0, B, 1e-12)
+        true_rel = np.linalg.norm(B.T - p.A @ X.T, axis=0) / np.linalg.norm(B.T, axis=0)
+        assert true_rel.max() < 5e-12, true_rel
+        assert relres.max() < 1e-12
+        assert iters.min() >= 1
+        ref = np.stack([p.lu_solver(0)(B[k]) for k in range(B.shape[0])])
+        assert _relerr(X, ref) < tol_x
+    # solves that start on a coarse level of the reference hierarchy (MLMC level-2 solves)
+    n2 = p128.levels[2].A.shape[0]
+    B = _rand((4, n2), 51)
+    X, iters, relres = p128.mg.solve_batch(2, B, 1e-12)
+    true_rel = np.linalg.norm(B.T - p128.levels[2].A @ X.T, axis=0) / np.linalg.norm(B.T, axis=0)
+    assert true_rel.max() < 5e-12
+
+
+def test_zero_rhs_and_single_rhs(p16):
+    n = p16.A.shape[0]
+    x, its, rr = p16.eng.solve(SOLVER_HID, 0, np.zeros(n, dtype=complex), 1e-12, 100)
+    assert np.all(x == 0) and its == 0
+    b = _rand(n, 60)
+    p16.mg.level_nr = 0
+    p16.mg.solve(p16.A, b, 1e-12)
+    assert np.linalg.norm(b - p16.A @ p16.mg.x) / np.linalg.norm(b) < 5e-12
+    assert p16.mg.num_iters >= 1
+
+
+@pytest.mark.parametrize("prob,use_perm", [("p16", False), ("p128", True)])
+def test_hutchinson_probes_match_lu_oracle(prob, use_perm, request):
+    """per-probe e_k against the direct-LU oracle, 1e-10 relative (north star)."""
+    p = request.getfixturevalue(prob)
+    n = p.A.shape[0]
+    np.random.seed(123456)
+    probes = utils.draw_probes(12, n)
+    ests, itf, _ = p.eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    PT = p.levels[0].Pperm.transpose() if use_perm else None
+    lu = p.lu_solver(0)
+    for k in range(12):
+        ref = rp.hutch_probe(probes[k].astype(np.complex128), lu, p.Ux, PT)
+        assert abs(ests[k] - ref) / abs(ref) < 1e-10, (k, ests[k], ref)
+    assert itf.min() >= 1
+
+
+def test_hutchinson_without_deflation(p16):
+    n = p16.A.shape[0]
+    np.random.seed(7)
+    probes = utils.draw_probes(5, n)
+    p16.eng.set_deflation(None)
+    try:
+        ests, _, _ = p16.eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    finally:
+        p16.eng.set_deflation(np.asarray(p16.Ux))
+    lu = p16.lu_solver(0)
+    for k in range(5):
+        ref = rp.hutch_probe(probes[k].astype(np.complex128), lu, None, None)
+        assert abs(ests[k] - ref) / abs(ref) < 1e-10
+
+
+def test_mlmc_probes_match_lu_oracle(p128):
+    """MLMC difference levels 0 (with level skipping) and 2 against exact level inverses."""
+    p = p128
+    cinv = np.asarray(p.mg.coarsest_inv)
+
+    def solve_level(l, b):
+        return p.lu_solver(l)(b)
+
+    for level, mode, skip in ((0, MODE_MLMC_SKIP, True), (2, MODE_MLMC, False), (0, MODE_MLMC, False)):
+        n = p.levels[level].A.shape[0]
+        np.random.seed(1000 + level)
+        probes = utils.draw_probes(6, n)
+        ests, itf, itc = p.eng.hutch_batch(mode, level, probes, 1e-12, 1000)
+        scale = None
+        for k in range(6):
+            x0 = probes[k].astype(np.complex128)
+            ref = rp.mlmc_probe(x0, level, p.levels, skip, solve_level, cinv, True)
+            # differences of two O(100) numbers: tolerance relative to the minuend
+            z = solve_level(level, p.levels[level].Bblock_perm @ (p.levels[level].Pperm.transpose() @ x0))
+            scale = max(abs(np.vdot(x0, z)), abs(ref))
+            assert abs(ests[k] - ref) / scale < 1e-10, (level, k, ests[k], ref)
+
+
+def test_estimator_drop_in_hutchinson_16(p16, capsys):
+    """the drop-in hutchinson() on 16^2 reproduces the sequential reference loop evaluated
+    with exact (LU) solves on the same probe stream."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    lev0 = p16.levels[0]
+    Ux, tr1, Vx, Sy = rp.deflation_hutchinson(p16.A, lev0.g3, None, 8, 1e-9, False)
+    tp = dict(p16.tp)
+    tp['nr_deflat_vctrs'] = 8
+    tp['tol'] = 2.0e-2
+    tp['batch'] = 64
+    tp['deflation_eigenpairs'] = (Sy, Vx)     # same eigenpairs on both sides
+    res = stoch_trace.hutchinson(p16.A, tp)
+    capsys.readouterr()
+    lu = p16.lu_solver(0)
+    np.random.seed(123456)
+    rough = [rp.hutch_probe(rp.rademacher(p16.A.shape[0]), lu, Ux, None) for _ in range(5)]
+    rough_trace = np.sum(rough) / 5 + tr1
+    tol = abs(tp['tol'] * rough_trace)
+    ests = np.array([rp.hutch_probe(rp.rademacher(p16.A.shape[0]), lu, Ux, None)
+                     for _ in range(res['nr_ests'] + 1)])
+    idx, avg, dev = rp.stopping_rule(ests, tol)
+    assert idx == res['nr_ests']
+    assert abs((avg + tr1) - res['trace']) / abs(avg + tr1) < 1e-9
+    assert abs(dev - res['std_dev']) / dev < 1e-8
+
+
+def test_timers_and_launch_count(p16):
+    p16.eng.set_profiling(True)
+    p16.eng.timers_reset()
+    B = _rand((2, p16.A.shape[0]), 70)
+    p16.mg.solve_batch(0, B, 1e-10)
+    t = p16.eng.timers()
+    p16.eng.set_profiling(False)
+    assert t["mvm"] > 0 and t["dots"] > 0 and t["axpy"] > 0
+    assert p16.eng.launch_count() > 10
+
+
+def test_bench_dirac_runs(p128):
+    ms = p128.eng.bench_dirac(REF_HID, 0, 256, 5)
+    assert 0 < ms < 50

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Hutchinson probe-samples/s on schwinger128 (BASELINE.json).
+
+One step = one batch of NB (default 256) deflated-Hutchinson probes per GPU, solved as one
+multi-RHS batch in fp64 to a relative residual of 1e-12 (config 2 of BASELINE.json; with
+--gpus N the probe stream is sharded in contiguous blocks over N ranks, config 4).  The
+probes of every step are generated and uploaded to HBM before the timed region.  The line
+printed by rank 0 also carries
+
+* ``roofline``: achieved algorithmic HBM rate of the batched Wilson stencil kernel, from
+  HIP-event timings of that kernel on the engine's stream in an instrumented extra step of
+  the same workload (kept out of the timed region so the events do not perturb ``value``);
+* ``cpu_baseline``: the oracle's reference-faithful NumPy/SciPy path timed on this host
+  (rank 0, N = 1 only, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nb", type=int, default=256, help="probes per GPU per step")
+    ap.add_argument("--tol", type=float, default=1e-12)
+    ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
+                    help="JSON solver-hierarchy override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-probes", type=int, default=2)
+    ap.add_argument("--quiet-setup", action="store_true", default=True)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as td
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+
+    from deflatedmlmc_schwinger_amd import dist as swdist
+    from deflatedmlmc_schwinger_amd import gateway, matrix, utils
+    from deflatedmlmc_schwinger_amd.engine import MODE_HUTCHINSON, ProbeStream
+    from deflatedmlmc_schwinger_amd.multigrid import MG, REF_HID
+
+    # ---- setup (untimed): operands, hierarchies, deflation vectors --------------------
+    import contextlib
+    import io
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = args.tol
+    params['device'] = local_rank
+    if args.cfg:
+        params['solver_cfg'] = json.loads(args.cfg)
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "hutchinson")
+    t_setup = time.time()
+    mg = MG(A)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+                 acc_eigvs=tp['accuracy_mg_eigvs'], sys_type=tp['problem_name'], params=tp)
+        Ux, tr1 = utils.deflation_pre_computations(A, tp['nr_deflat_vctrs'],
+                                                   tp['defl_eigvs_tol_Hutch'], "hutchinson",
+                                                   mg.timer, tp, mg)
+    t_setup = time.time() - t_setup
+    eng = mg.engine
+    n = A.shape[0]
+    L = mg.lattice[0]
+    V = L * L
+    nb = args.nb
+    nbp = ((nb + 63) // 64) * 64
+    maxiter = 1000
+
+    # ---- inputs: probes of every step, resident in HBM before timing ---------------------
+    nsteps = args.warmup + args.steps + 1          # +1: instrumented step
+    stream = ProbeStream(123456)
+    for s in range(nsteps):
+        stream.skip(rank * nb * n)
+        probes = stream.rademacher(nb, n)
+        stream.skip((world - 1 - rank) * nb * n)
+        eng.probes_upload_slot(s, 0, probes)
+    comm = swdist.TorchComm() if world > 1 else swdist.Comm()
+
+    def step(s):
+        eng.probes_select(s)
+        eng.hutch_run(MODE_HUTCHINSON, 0, args.tol, maxiter)
+        ests, itf, _ = eng.hutch_fetch()
+        stats = comm.allreduce_stats(swdist.local_stats(ests))
+        return ests, itf, stats
+
+    for s in range(args.warmup):
+        step(s)
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = np.zeros(4)
+    iters_seen = []
+    for s in range(args.warmup, args.warmup + args.steps):
+        ests, itf, stats = step(s)
+        total += stats
+        iters_seen.append(int(itf.max()))
+    comm.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- instrumented step: HIP events around every launch, on the engine stream ----------
+    eng.set_profiling(True)
+    eng.timers_reset()
+    step(args.warmup + args.steps)
+    st_ms, st_cnt = eng.kernel_stats(8)
+    buckets = eng.timers()
+    launches = eng.launch_count()
+    eng.set_profiling(False)
+    # back-to-back stencil launches (no other kernels in between), same buffers
+    dirac_ms = eng.bench_dirac(REF_HID, 0, nb, 50)
+
+    if rank == 0:
+        mean, std = swdist.mean_and_population_std(total)
+        bytes_per_launch = V * (64.0 * nbp + 32.0)
+        avg_ms = st_ms / max(st_cnt, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "stencil_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "hutchinson_probe_samples_per_sec_schwinger128",
+            "value": world * args.steps * nb / elapsed,
+            "unit": "probe-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic Rademacher probes (MT19937 seed 123456) on the schwinger128 gauge "
+                    "configuration (link fixture), m0=-0.1320",
+            "config": {
+                "workload": "schwinger128, %d probes/GPU/step as one multi-RHS batch, deflated "
+                            "Hutchinson (k=8, Pperm shift 512), fp64, tol %.0e" % (nb, args.tol),
+                "probes_per_step_per_gpu": nb,
+                "solver": mg.solver_info,
+                "outer_iterations_max": max(iters_seen) if iters_seen else None,
+                "trace_estimate": [float(np.real(mean + tr1)), float(np.imag(mean + tr1))],
+                "std_dev": std,
+                "setup_s": t_setup,
+            },
+            "roofline": {
+                "kernel": "k_stencil (batched Wilson-Schwinger stencil, level 0)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_ms,
+                "launches_in_step": st_cnt,
+                "back_to_back_ms": dirac_ms,
+                "back_to_back_GBs": bytes_per_launch / (dirac_ms * 1e-3) / 1e9,
+            },
+            "step_breakdown_ms": dict(buckets, stencil=st_ms, kernel_launches=launches),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes)
+        print(json.dumps(out))
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def cpu_baseline(A, tp, mg, nprobes):
+    """The oracle's reference-faithful path (SciPy CSR + lgmres(maxiter=2) smoother + flexible
+    GMRES, tol 1e-12, OMP_NUM_THREADS=1 as main.py:20 forces) on a bounded sample."""
+    from oracle import ref_path as rp
+    omg = rp.OracleMG(A)
+    omg.setup(tp['dof'], tp['aggrs'], tp['max_nr_levels'], tp['accuracy_mg_eigvs'], tp,
+              testvectors=mg.testvectors)
+    lev0 = omg.ml.levels[0]
+    Ux, _, _, _ = rp.deflation_hutchinson(A, lev0.g3, lev0.Pperm, tp['nr_deflat_vctrs'],
+                                          tp['defl_eigvs_tol_Hutch'], True)
+    PT = lev0.Pperm.transpose()
+
+    def solve(b):
+        omg.level_nr = 0
+        omg.solve(A, b, tp['function_params']['tol'])
+        return omg.x
+
+    np.random.seed(123456)
+    t0 = time.perf_counter()
+    for _ in range(nprobes):
+        rp.hutch_probe(rp.rademacher(A.shape[0]), solve, Ux, PT)
+    dt = time.perf_counter() - t0
+    return {"value": nprobes / dt, "unit": "probe-samples/s", "cores": 1, "kind": "port",
+            "sample": "%d deflated Hutchinson probes of the same workload (setup excluded), "
+                      "oracle/ref_path.py restatement of the reference path, 1 thread of %d host "
+                      "cores" % (nprobes, os.cpu_count() or 0),
+            "seconds": dt}
+
+
+if __name__ == "__main__":
+    main()

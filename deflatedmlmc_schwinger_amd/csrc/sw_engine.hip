@@ -38,7 +38,8 @@ static int sw_fail(sw_engine* h, const char* fmt, ...);
     if (rc_ != 0) return rc_;   \
   } while (0)
 
-enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER, T_NCAT };
+enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER, T_STENCIL, T_NCAT };
+// T_STENCIL is reported inside the mvm bucket by sw_timers and separately by sw_kernel_stats
 
 struct EllOp {
   int nrows = 0, ncols = 0, K = 0, G = 1, ngroups = 0;
@@ -68,6 +69,9 @@ struct Level {
   cplx* U2 = nullptr;
   EllOp A, P, R;
   int nu_pre = 0, nu_post = 3, kcycle = 0;
+  // fixed-polynomial (Richardson) smoother: weights 1/theta_k; empty -> adaptive MR steps
+  std::vector<std::complex<double>> w_pre, w_post;
+  bool rich = false;
   std::vector<int> h_rowmap;  // natural -> internal (empty: identity)
   int* rowmap = nullptr;
   // per-level cycle workspace, [n][nbp]
@@ -81,6 +85,8 @@ struct Hier {
   int nlevels = 0;
   Level lv[SW_MAX_LEVELS];
   EllOp cinv;
+  cplx* cinv_packed = nullptr;   // MFMA layout (n % 16 == 0)
+  int cinv_n = 0;
   bool ready = false;
 };
 
@@ -112,8 +118,13 @@ struct sw_engine {
   std::vector<std::pair<void*, size_t>> allocs;
   // probe batch state
   int pb_level = -1, pb_nb = 0, pb_nbp = 0;
-  int8_t* pb_probes = nullptr;
-  size_t pb_probes_bytes = 0;
+  int8_t* pb_probes = nullptr;   // currently selected slot
+  struct ProbeSlot {
+    int8_t* p = nullptr;
+    size_t bytes = 0;
+    int level = -1, nb = 0;
+  };
+  std::vector<ProbeSlot> slots;
   cplx *pb_x0 = nullptr, *pb_rhs = nullptr, *pb_z = nullptr, *pb_xc = nullptr, *pb_xc2 = nullptr,
        *pb_y = nullptr, *pb_w = nullptr, *pb_w2 = nullptr;
   int pb_ws_nbp = 0;
@@ -125,6 +136,7 @@ struct sw_engine {
   std::vector<EventRec> recs;
   std::vector<hipEvent_t> evpool;
   double tacc[T_NCAT] = {0};
+  int64_t tcount[T_NCAT] = {0};
   int64_t launches = 0;
   int* d_notconv = nullptr;
   int* h_notconv = nullptr;  // pinned
@@ -230,7 +242,10 @@ struct LaunchScope {
 static void harvest_events(sw_engine* h) {
   for (auto& r : h->recs) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) h->tacc[r.cat] += ms;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      h->tacc[r.cat] += ms;
+      h->tcount[r.cat] += 1;
+    }
     h->evpool.push_back(r.e0);
     h->evpool.push_back(r.e1);
   }
@@ -326,7 +341,7 @@ static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_
 // kernel launch wrappers
 // ---------------------------------------------------------------------------------------------
 static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B,
-                      cplx* Y, int nbp, int cat) {
+                      cplx* Y, int nbp, int cat, cplx w = cplx{0.0, 0.0}) {
   if (!op.set) return sw_fail(h, "operator not set");
   dim3 grid((op.ngroups + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
   LaunchScope ls(h, cat);
@@ -334,13 +349,16 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   case GG:                                                                                      \
     if (mode == 0)                                                                              \
       hipLaunchKernelGGL((swk::k_ell<GG, 0>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp);         \
+                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
     else if (mode == 1)                                                                         \
       hipLaunchKernelGGL((swk::k_ell<GG, 1>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp);         \
-    else                                                                                        \
+                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
+    else if (mode == 2)                                                                         \
       hipLaunchKernelGGL((swk::k_ell<GG, 2>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp);         \
+                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
+    else                                                                                        \
+      hipLaunchKernelGGL((swk::k_ell<GG, 3>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
+                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
     break;
   switch (op.G) {
     ELL_CASE(1)
@@ -356,14 +374,29 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   return 0;
 }
 
+// Y = coarsest_inv X : fp64 MFMA kernel when the size allows, grouped-ELL otherwise
+static int apply_coarsest(sw_engine* h, Hier& H, const cplx* X, cplx* Y, int nbp) {
+  if (!H.cinv.set) return sw_fail(h, "coarsest inverse not set");
+  if (H.cinv_packed && (nbp % 16) == 0) {
+    const int n = H.cinv_n;
+    dim3 grid((n / 16 + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, (2 * nbp) / 32);
+    LaunchScope ls(h, T_COARSEST);
+    hipLaunchKernelGGL(swk::k_dense_mfma, grid, dim3(SW_BLOCK), 0, h->stream,
+                       (const cplx*)H.cinv_packed, n, (const double*)X, (double*)Y, 2 * nbp);
+    KLAUNCH_CHECK();
+    return 0;
+  }
+  return launch_ell(h, H.cinv, 0, X, nullptr, Y, nbp, T_COARSEST);
+}
+
 static int stencil_spw(int L) {
   // consecutive x-sites per wave: keep >= 8 workgroups per CU worth of blocks on 128^2
   return 1;
 }
 
-// Y = A X (mode 0) or Y = B - A X (mode 1) at a level
+// Y = A X (mode 0), Y = B - A X (mode 1) or Y = X + w (B - A X) (mode 2) at a level
 static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* B, cplx* Y,
-                    int nbp) {
+                    int nbp, cplx w = cplx{0.0, 0.0}) {
   if (lv.stencil) {
     swk::StencilArgs a;
     a.L = lv.L;
@@ -373,28 +406,32 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     a.U2 = lv.U2;
     a.nbp = nbp;
     a.sites_per_wave = stencil_spw(lv.L);
+    a.w = w;
     const int V = lv.L * lv.L;
     const int waves = V / a.sites_per_wave;
     const int bpc = (waves + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
     const int nchunks = nbp / 64;
-    LaunchScope ls(h, T_MVM);
+    LaunchScope ls(h, T_STENCIL);
     if (mode == 0)
       hipLaunchKernelGGL((swk::k_stencil<0>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
                          X, B, Y, a, bpc);
-    else
+    else if (mode == 1)
       hipLaunchKernelGGL((swk::k_stencil<1>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
+                         X, B, Y, a, bpc);
+    else
+      hipLaunchKernelGGL((swk::k_stencil<2>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
                          X, B, Y, a, bpc);
     KLAUNCH_CHECK();
     return 0;
   }
-  return launch_ell(h, lv.A, mode, X, B, Y, nbp, T_MVM);
+  return launch_ell(h, lv.A, mode == 2 ? 3 : mode, X, B, Y, nbp, T_MVM, w);
 }
 
 static void row_blocking(int n, int nbp, bool reduce, int* P, int* rpb) {
   const int nchunks = nbp / 64;
   int p;
   if (reduce) {
-    p = std::max(8, std::min(256, 1024 / std::max(1, nchunks)));
+    p = std::max(8, std::min(128, 512 / std::max(1, nchunks)));
   } else {
     p = std::max(8, 4096 / std::max(1, nchunks));
   }
@@ -428,9 +465,8 @@ static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n,
   }
   {
     LaunchScope ls(h, T_DOTS);
-    const int tot = K * nbp;
-    hipLaunchKernelGGL(swk::k_reduce_partials, dim3((tot + SW_BLOCK - 1) / SW_BLOCK),
-                       dim3(SW_BLOCK), 0, h->stream, h->partial, P, K, nbp, out);
+    hipLaunchKernelGGL(swk::k_reduce_partials, dim3(K, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
+                       h->partial, P, K, nbp, out);
     KLAUNCH_CHECK();
   }
   return 0;
@@ -466,8 +502,8 @@ static int multiaxpy(sw_engine* h, const PtrList& V, int K, const cplx* coef, do
   }
   if (nrm_out) {
     LaunchScope ls(h, T_DOTS);
-    hipLaunchKernelGGL(swk::k_reduce_partials, dim3((nbp + SW_BLOCK - 1) / SW_BLOCK),
-                       dim3(SW_BLOCK), 0, h->stream, h->partial, P, 1, nbp, nrm_out);
+    hipLaunchKernelGGL(swk::k_reduce_partials, dim3(1, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
+                       h->partial, P, 1, nbp, nrm_out);
     KLAUNCH_CHECK();
   }
   return 0;
@@ -608,11 +644,35 @@ static int mr_smooth(sw_engine* h, Level& lv, cplx* X, cplx* R, int nu, int nbp)
   return 0;
 }
 
+// n fixed-weight Richardson steps  x <- x + w_k (B - A x), ping-ponging between `cur`
+// (holding x on entry, ignored when from_zero) and `other`; *result = buffer with the answer
+static int rich_steps(sw_engine* h, Level& lv, const cplx* Bin, cplx* cur, cplx* other,
+                      const std::vector<std::complex<double>>& w, bool from_zero, int nbp,
+                      cplx** result) {
+  size_t k = 0;
+  if (from_zero && !w.empty()) {
+    LaunchScope ls(h, T_AXPY);
+    const size_t count = (size_t)lv.n * nbp;
+    hipLaunchKernelGGL(swk::k_cscale, dim3(2048), dim3(SW_BLOCK), 0, h->stream,
+                       cplx{w[0].real(), w[0].imag()}, Bin, cur, count);
+    KLAUNCH_CHECK();
+    k = 1;
+  }
+  for (; k < w.size(); ++k) {
+    SWCHK(apply_op(h, lv, 2, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()}));
+    std::swap(cur, other);
+  }
+  *result = cur;
+  return 0;
+}
+
+static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp);
+
 static int vcycle(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
+  if (l < H.nlevels - 1 && H.lv[l].rich) return vcycle_rich(h, H, l, Bin, Xout, nbp);
   const int last = H.nlevels - 1;
   if (l == last) {
-    if (!H.cinv.set) return sw_fail(h, "coarsest inverse not set");
-    return launch_ell(h, H.cinv, 0, Bin, nullptr, Xout, nbp, T_COARSEST);
+    return apply_coarsest(h, H, Bin, Xout, nbp);
   }
   Level& lv = H.lv[l];
   Level& lc = H.lv[l + 1];
@@ -640,6 +700,45 @@ static int vcycle(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int
     SWCHK(apply_op(h, lv, 1, Xout, Bin, lv.r, nbp));
     SWCHK(mr_smooth(h, lv, Xout, lv.r, lv.nu_post, nbp));
   }
+  return 0;
+}
+
+static int coarse_correction(sw_engine* h, Hier& H, int l, int nbp) {
+  Level& lv = H.lv[l];
+  Level& lc = H.lv[l + 1];
+  const int last = H.nlevels - 1;
+  if (lv.kcycle > 0 && l + 1 < last) {
+    SWCHK(ensure_krylov(h, lc.kws, lv.kcycle, lc.n, nbp, false));
+    return fgmres(h, H, l + 1, lc.b, lc.x, 0.0, lv.kcycle, lv.kcycle, false, lc.kws, nbp, nullptr);
+  }
+  return vcycle(h, H, l + 1, lc.b, lc.x, nbp);
+}
+
+// cycle with the fixed-polynomial smoother (weights set by sw_set_smoother)
+static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
+  Level& lv = H.lv[l];
+  Level& lc = H.lv[l + 1];
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  SWCHK(ensure_level_ws(h, lc, nbp));
+  if (!lv.P.set || !lv.R.set) return sw_fail(h, "transfer operators of level %d not set", l);
+  const size_t npost = lv.w_post.size();
+  cplx* xpre = nullptr;
+  if (!lv.w_pre.empty()) {
+    SWCHK(rich_steps(h, lv, Bin, Xout, lv.t, lv.w_pre, true, nbp, &xpre));
+    SWCHK(apply_op(h, lv, 1, xpre, Bin, lv.r, nbp));
+    SWCHK(launch_ell(h, lv.R, 0, lv.r, nullptr, lc.b, nbp, T_R));
+  } else {
+    SWCHK(launch_ell(h, lv.R, 0, Bin, nullptr, lc.b, nbp, T_R));
+  }
+  SWCHK(coarse_correction(h, H, l, nbp));
+  // place the prolongated iterate so that npost ping-pong steps end in Xout
+  cplx* start = (npost % 2 == 0) ? Xout : lv.t;
+  cplx* other = (npost % 2 == 0) ? lv.t : Xout;
+  if (xpre) SWCHK(launch_ell(h, lv.P, 2, lc.x, xpre, start, nbp, T_P));
+  else SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, start, nbp, T_P));
+  cplx* res = start;
+  SWCHK(rich_steps(h, lv, Bin, start, other, lv.w_post, false, nbp, &res));
+  if (res != Xout) SWCHK(copy_vec(h, Xout, res, lv.n, nbp));
   return 0;
 }
 
@@ -859,6 +958,8 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     lv = Level();
   }
   SWCHK(dev_free(h, H.cinv.cols)); SWCHK(dev_free(h, H.cinv.vals));
+  SWCHK(dev_free(h, H.cinv_packed));
+  H.cinv_packed = nullptr;
   H.cinv = EllOp();
   H.nlevels = nlevels;
   H.ready = false;
@@ -979,6 +1080,19 @@ int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense) {
   SWCHK(upload(h, &op.cols, hc.data(), hc.size()));
   SWCHK(upload(h, (std::complex<double>**)&op.vals, hv.data(), hv.size()));
   op.set = true;
+  SWCHK(dev_free(h, H.cinv_packed));
+  H.cinv_packed = nullptr;
+  H.cinv_n = n;
+  if (n % 16 == 0) {
+    const int KS = n / 4, RT = n / 16;
+    std::vector<std::complex<double>> pk((size_t)RT * KS * 64);
+    for (int rt = 0; rt < RT; ++rt)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          pk[((size_t)rt * KS + ks) * 64 + lane] =
+              M[(size_t)(rt * 16 + (lane & 15)) * n + ks * 4 + (lane >> 4)];
+    SWCHK(upload(h, (std::complex<double>**)&H.cinv_packed, pk.data(), pk.size()));
+  }
   return 0;
 }
 
@@ -990,6 +1104,21 @@ int sw_set_cycle(sw_engine* h, int hid, int level, int nu_pre, int nu_post, int 
   lv.nu_pre = nu_pre;
   lv.nu_post = nu_post;
   lv.kcycle = kcycle;
+  return 0;
+}
+
+int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w_pre, int n_post,
+                    const double* w_post) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (n_pre < 0 || n_post < 0 || n_pre > 64 || n_post > 64)
+    return sw_fail(h, "sw_set_smoother: bad step counts");
+  if ((n_pre > 0 && !w_pre) || (n_post > 0 && !w_post)) return sw_fail(h, "null weights");
+  Level& lv = h->hier[hid].lv[level];
+  lv.w_pre.clear();
+  lv.w_post.clear();
+  for (int i = 0; i < n_pre; ++i) lv.w_pre.emplace_back(w_pre[2 * i], w_pre[2 * i + 1]);
+  for (int i = 0; i < n_post; ++i) lv.w_post.emplace_back(w_post[2 * i], w_post[2 * i + 1]);
+  lv.rich = (n_pre + n_post) > 0;
   return 0;
 }
 
@@ -1103,7 +1232,7 @@ static int simple_op(sw_engine* h, int hid, int level, int nb, const double* X, 
     Level& ll = H.lv[H.nlevels - 1];
     SWCHK(io_vectors(h, ll, nbp, &a, &b));
     SWCHK(pack_host(h, ll, nb, X, a, nbp));
-    SWCHK(launch_ell(h, H.cinv, 0, a, nullptr, b, nbp, T_COARSEST));
+    SWCHK(apply_coarsest(h, H, a, b, nbp));
     return unpack_host(h, ll, nb, b, Y, nbp);
   }
   if (level + 1 >= H.nlevels) return sw_fail(h, "no transfer at the coarsest level");
@@ -1155,7 +1284,7 @@ static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, 
   Level& lv = H.lv[level0];
   if (level0 == H.nlevels - 1 && H.nlevels > 1) {
     // coarsest level: the dense inverse is the solve (multigrid.py:413-416)
-    SWCHK(launch_ell(h, H.cinv, 0, B, nullptr, X, nbp, T_COARSEST));
+    SWCHK(apply_coarsest(h, H, B, X, nbp));
     if (total) *total = 1;
     return 0;
   }
@@ -1222,26 +1351,44 @@ static int ensure_probe_ws(sw_engine* h, int nbp) {
   return 0;
 }
 
-int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes) {
+int sw_probes_upload_slot(sw_engine* h, int slot, int level, int nb, const int8_t* probes) {
   SWCHK(check_hier(h, 0, level, true));
   if (nb <= 0 || !probes) return sw_fail(h, "bad arguments");
+  if (slot < 0 || slot >= 4096) return sw_fail(h, "probe slot %d out of range", slot);
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[0].lv[level];
   const size_t bytes = (size_t)nb * lv.n;
-  if (h->pb_probes_bytes < bytes) {
-    SWCHK(dev_free(h, h->pb_probes));
-    h->pb_probes = nullptr;
+  if ((int)h->slots.size() <= slot) h->slots.resize(slot + 1);
+  sw_engine::ProbeSlot& sl = h->slots[slot];
+  if (sl.bytes < bytes) {
+    SWCHK(dev_free(h, sl.p));
+    sl.p = nullptr;
     void* q;
     SWCHK(dev_alloc(h, &q, bytes));
-    h->pb_probes = (int8_t*)q;
-    h->pb_probes_bytes = bytes;
+    sl.p = (int8_t*)q;
+    sl.bytes = bytes;
   }
-  HIPCHK(hipMemcpyAsync(h->pb_probes, probes, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(sl.p, probes, bytes, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->pb_level = level;
-  h->pb_nb = nb;
-  h->pb_nbp = pad64(nb);
+  sl.level = level;
+  sl.nb = nb;
   return 0;
+}
+
+int sw_probes_select(sw_engine* h, int slot) {
+  if (!h) return 1;
+  if (slot < 0 || slot >= (int)h->slots.size() || !h->slots[slot].p)
+    return sw_fail(h, "probe slot %d is empty", slot);
+  h->pb_probes = h->slots[slot].p;
+  h->pb_level = h->slots[slot].level;
+  h->pb_nb = h->slots[slot].nb;
+  h->pb_nbp = pad64(h->pb_nb);
+  return 0;
+}
+
+int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes) {
+  SWCHK(sw_probes_upload_slot(h, 0, level, nb, probes));
+  return sw_probes_select(h, 0);
 }
 
 static int dot_into(sw_engine* h, const cplx* A, const cplx* Bv, int n, int nbp, cplx* out) {
@@ -1309,10 +1456,8 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
         }
         {
           LaunchScope ls(h, T_DEFL);
-          const int tot = kc * nbp;
-          hipLaunchKernelGGL(swk::k_reduce_partials, dim3((tot + SW_BLOCK - 1) / SW_BLOCK),
-                             dim3(SW_BLOCK), 0, h->stream, h->partial, P, kc, nbp,
-                             cbuf + (size_t)k0 * nbp);
+          hipLaunchKernelGGL(swk::k_reduce_partials, dim3(kc, nbp / 64), dim3(SW_BLOCK), 0,
+                             h->stream, h->partial, P, kc, nbp, cbuf + (size_t)k0 * nbp);
           KLAUNCH_CHECK();
         }
       }
@@ -1468,13 +1613,25 @@ int sw_timers(sw_engine* h, double t[8]) {
   if (!h || !t) return 1;
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
+  t[T_MVM] += h->tacc[T_STENCIL];
   return 0;
 }
 int sw_timers_reset(sw_engine* h) {
   if (!h) return 1;
   SWCHK(stream_sync(h));
-  for (int i = 0; i < T_NCAT; ++i) h->tacc[i] = 0.0;
+  for (int i = 0; i < T_NCAT; ++i) {
+    h->tacc[i] = 0.0;
+    h->tcount[i] = 0;
+  }
   h->launches = 0;
+  return 0;
+}
+int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches) {
+  if (!h || !total_ms || !launches) return 1;
+  if (which < 0 || which >= T_NCAT) return sw_fail(h, "kernel class %d out of range", which);
+  SWCHK(stream_sync(h));
+  *total_ms = h->tacc[which];
+  *launches = h->tcount[which];
   return 0;
 }
 int sw_launch_count(sw_engine* h, int64_t* n) {

@@ -59,9 +59,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 // SpMV of multigrid.py:552-557 / matrix.py:21-29).  One wave = one lattice site x 64 probes.
 //   (S psi)(n) = 4 psi(n) - [ (1-s1) U1(n) psi(n+x) + (1+s1) U1*(n-x) psi(n-x)
 //                           + (1-s2) U2(n) psi(n+y) + (1+s2) U2*(n-y) psi(n-y) ]
-// MODE 0: Y = A X      MODE 1: Y = B - A X
-// DOTS: also accumulate, per probe, d0 = sum conj(Q) * Y and d1 = sum |Y|^2 over the rows of
-// this workgroup (Q = B argument when MODE 0 ... see k_stencil body), written to `partial`.
+// MODE 0: Y = A X      MODE 1: Y = B - A X      MODE 2: Y = X + w (B - A X)  (one fused
+// Richardson/polynomial-smoother step: 3 vector passes, no inner products)
 // ------------------------------------------------------------------------------------------
 struct StencilArgs {
   int L;          // lattice extent (even)
@@ -71,6 +70,7 @@ struct StencilArgs {
   const cplx* U2;
   int nbp;
   int sites_per_wave;  // consecutive x-sites handled by one wave
+  cplx w;              // MODE 2 relaxation weight
 };
 
 __device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
@@ -139,6 +139,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
       o0 = csub(q0, o0);
       o1 = csub(q1, o1);
     }
+    if (MODE == 2) {
+      const cplx q0 = B[r_c * nbp + col], q1 = B[(r_c + 1) * nbp + col];
+      cplx t0 = c0, t1 = c1;
+      cfma(t0, a.w, csub(q0, o0));
+      cfma(t1, a.w, csub(q1, o1));
+      o0 = t0;
+      o1 = t1;
+    }
     Y[r_c * nbp + col] = o0;
     Y[(r_c + 1) * nbp + col] = o1;
   }
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
 // X row is loaded once and used G times with wave-uniform (scalar) coefficients.
 //   cols [ngroups][K]   vals [ngroups][K][G]   (padding: col 0, val 0)
 // MODE 0: Y = A X      MODE 1: Y = B - A X      MODE 2: Y = B + A X
+// MODE 3: Y = X + w (B - A X)   (square operators only)
 // ------------------------------------------------------------------------------------------
 template <int G, int MODE>
 __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
                                                   int ngroups, const int* __restrict__ rowmap,
                                                   const cplx* __restrict__ X,
                                                   const cplx* __restrict__ B,
-                                                  cplx* __restrict__ Y, int nbp) {
+                                                  cplx* __restrict__ Y, int nbp, cplx w) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int grp = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + wave);
@@ -184,7 +193,59 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
     cplx o = acc[g];
     if (MODE == 1) o = csub(B[row * nbp + col], o);
     if (MODE == 2) o = cadd(B[row * nbp + col], o);
+    if (MODE == 3) {
+      cplx t = X[row * nbp + col];
+      cfma(t, w, csub(B[row * nbp + col], o));
+      o = t;
+    }
     Y[row * nbp + col] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense coarsest-level inverse (multigrid.py:413-416) on the fp64 matrix cores:
+//   Y[n][nbp] = M[n][n] * X[n][nbp]   (complex128)
+// v_mfma_f64_16x16x4_f64:  D(16x16) += A(16x4) B(4x16),  lane l holds A[l&15][l>>4],
+// B[l>>4][l&15] and D[(l>>4)+4r][l&15], r<4 (cdna_hip_programming.md section 3).
+// X and Y are used as REAL [n][2*nbp] matrices (re/im interleaved along the row), so one
+// 16-column MFMA tile covers 8 probes.  Two accumulators per tile: D1 = Re(M) X'', D2 = Im(M) X'';
+//   Y''[i][2j] = D1[i][2j] - D2[i][2j+1],   Y''[i][2j+1] = D1[i][2j+1] + D2[i][2j]
+// i.e. one neighbour-lane exchange in the epilogue.  M is pre-packed at upload time so every
+// k-step of a 16-row tile is one coalesced 1-KiB read:  Mp[(rt*KS + ks)*64 + lane] =
+// M[rt*16 + (lane&15)][ks*4 + (lane>>4)].   One wave = 16 rows x 32 real columns (16 probes).
+// ------------------------------------------------------------------------------------------
+typedef double sw_double4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(SW_BLOCK) void k_dense_mfma(const cplx* __restrict__ Mp, int n,
+                                                         const double* __restrict__ Xr,
+                                                         double* __restrict__ Yr, int ld) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rt = blockIdx.x * SW_WAVES_PER_BLOCK + wave;
+  if (rt * 16 >= n) return;
+  const int c0 = blockIdx.y * 32;
+  const int KS = n / 4;
+  const cplx* a = Mp + (size_t)rt * KS * 64 + lane;
+  const double* b = Xr + (size_t)(lane >> 4) * ld + c0 + (lane & 15);
+  sw_double4 re0 = {0.0, 0.0, 0.0, 0.0}, im0 = re0, re1 = re0, im1 = re0;
+#pragma unroll 4
+  for (int ks = 0; ks < KS; ++ks) {
+    const cplx m = a[(size_t)ks * 64];
+    const double x0 = b[(size_t)ks * 4 * ld];
+    const double x1 = b[(size_t)ks * 4 * ld + 16];
+    re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.x, x0, re0, 0, 0, 0);
+    im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.y, x0, im0, 0, 0, 0);
+    re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.x, x1, re1, 0, 0, 0);
+    im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.y, x1, im1, 0, 0, 0);
+  }
+  const int c = lane & 15;
+  const bool odd = (c & 1) != 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t row = (size_t)rt * 16 + (lane >> 4) + 4 * r;
+    const double s0 = __shfl_xor(im0[r], 1);
+    const double s1 = __shfl_xor(im1[r], 1);
+    Yr[row * ld + c0 + c] = odd ? re0[r] + s0 : re0[r] - s0;
+    Yr[row * ld + c0 + 16 + c] = odd ? re1[r] + s1 : re1[r] - s1;
   }
 }
 
@@ -260,7 +321,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_unpack_c(const cplx* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // Batched BLAS-1.  All of them: lane == probe, grid.y == 64-probe chunk.
 // ------------------------------------------------------------------------------------------
-#define SW_MAXK 49   // SW_MAX_KRYLOV + 1
+#define SW_MAXK 34   // restart cap 32, + w itself + 1
 
 struct PtrList {
   const cplx* p[SW_MAXK];
@@ -313,15 +374,39 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrList V, int K, const c
 }
 
 // out[k*nbp + col] = sum_p partial[(p*K + k)*nbp + col]
+// grid = (K, nbp/64); the four waves of a block take p = wave, wave+4, ... with independent
+// loads in flight, then combine through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(SW_BLOCK) void k_reduce_partials(const cplx* __restrict__ partial,
                                                               int P, int K, int nbp,
                                                               cplx* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= K * nbp) return;
-  const int k = idx / nbp, col = idx % nbp;
-  cplx s = cmake(0.0, 0.0);
-  for (int p = 0; p < P; ++p) s = cadd(s, partial[((size_t)p * K + k) * nbp + col]);
-  out[(size_t)k * nbp + col] = s;
+  __shared__ cplx red[3][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const size_t pstride = (size_t)K * nbp;
+  const cplx* src = partial + (size_t)k * nbp + col;
+  cplx s0 = cmake(0.0, 0.0), s1 = s0, s2 = s0, s3 = s0;
+  int p = wave;
+  for (; p + 12 < P; p += 16) {
+    const cplx a = src[(size_t)p * pstride];
+    const cplx b = src[(size_t)(p + 4) * pstride];
+    const cplx c = src[(size_t)(p + 8) * pstride];
+    const cplx d = src[(size_t)(p + 12) * pstride];
+    s0 = cadd(s0, a);
+    s1 = cadd(s1, b);
+    s2 = cadd(s2, c);
+    s3 = cadd(s3, d);
+  }
+  for (; p < P; p += 4) s0 = cadd(s0, src[(size_t)p * pstride]);
+  cplx s = cadd(cadd(s0, s1), cadd(s2, s3));
+  if (wave > 0) red[wave - 1][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    s = cadd(s, red[0][lane]);
+    s = cadd(s, red[1][lane]);
+    s = cadd(s, red[2][lane]);
+    out[(size_t)k * nbp + col] = s;
+  }
 }
 
 // Wout[r] = Win[r] + sign * sum_k coef[k][col] * V_k[r]; optionally partial |Wout|^2 sums
@@ -408,6 +493,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_scale(const cplx* __restrict__ s,
     const cplx v = src[off];
     dst[off] = cmake(f * v.x, f * v.y);
   }
+}
+
+// dst = w * src   (w one complex constant: first Richardson step from a zero guess)
+__global__ __launch_bounds__(SW_BLOCK) void k_cscale(cplx w, const cplx* __restrict__ src,
+                                                     cplx* __restrict__ dst, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) dst[i] = cmul(w, src[i]);
 }
 
 // dst[r] = src[srcrow[r]]  (row gather: the Pperm^T index shift in the internal row order)

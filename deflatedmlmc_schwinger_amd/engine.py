@@ -61,6 +61,7 @@ def load_library():
     sig("sw_set_transfer", i32, vp, i32, i32, i32, i32, vp, vp, vp)
     sig("sw_set_coarsest_inv", i32, vp, i32, i32, vp)
     sig("sw_set_cycle", i32, vp, i32, i32, i32, i32, i32)
+    sig("sw_set_smoother", i32, vp, i32, i32, i32, vp, i32, vp)
     sig("sw_hier_end", i32, vp, i32)
     sig("sw_set_deflation", i32, vp, i32, vp)
     sig("sw_set_perm", i32, vp, i32, i64)
@@ -74,6 +75,9 @@ def load_library():
     sig("sw_solve", i32, vp, i32, i32, i32, vp, vp, dbl, i32, vp, vp)
     sig("sw_hutch_batch", i32, vp, i32, i32, i32, vp, dbl, i32, vp, vp)
     sig("sw_probes_upload", i32, vp, i32, i32, vp)
+    sig("sw_probes_upload_slot", i32, vp, i32, i32, i32, vp)
+    sig("sw_probes_select", i32, vp, i32)
+    sig("sw_kernel_stats", i32, vp, i32, P(dbl), P(i64))
     sig("sw_hutch_run", i32, vp, i32, i32, dbl, i32)
     sig("sw_sync", i32, vp)
     sig("sw_hutch_fetch", i32, vp, vp, vp)
@@ -94,9 +98,10 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_hier_end", "sw_set_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver",
+    "sw_set_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
-    "sw_hutch_batch", "sw_probes_upload", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
+    "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
+    "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
     "sw_bench_dirac", "sw_set_profiling", "sw_timers", "sw_timers_reset", "sw_launch_count",
     "sw_mt_create", "sw_mt_destroy", "sw_mt_skip", "sw_mt_raw", "sw_mt_rademacher",
 )
@@ -194,6 +199,13 @@ class Engine:
     def set_cycle(self, hid, level, nu_pre, nu_post, kcycle=0):
         self._chk(self._lib.sw_set_cycle(self._h, hid, level, nu_pre, nu_post, kcycle),
                   "sw_set_cycle")
+
+    def set_smoother(self, hid, level, w_pre, w_post):
+        wp = _c128(np.asarray(w_pre if w_pre is not None else [], dtype=np.complex128))
+        wq = _c128(np.asarray(w_post if w_post is not None else [], dtype=np.complex128))
+        self._chk(self._lib.sw_set_smoother(self._h, hid, level, wp.size,
+                                            _ptr(wp) if wp.size else None, wq.size,
+                                            _ptr(wq) if wq.size else None), "sw_set_smoother")
 
     def hier_end(self, hid):
         self._chk(self._lib.sw_hier_end(self._h, hid), "sw_hier_end")
@@ -298,6 +310,24 @@ class Engine:
         self._nb_uploaded = p.shape[0]
         self._chk(self._lib.sw_probes_upload(self._h, level, p.shape[0], _ptr(p)),
                   "sw_probes_upload")
+
+    def probes_upload_slot(self, slot, level, probes):
+        p = self._probes(probes)
+        self._chk(self._lib.sw_probes_upload_slot(self._h, slot, level, p.shape[0], _ptr(p)),
+                  "sw_probes_upload_slot")
+        self._slot_nb = getattr(self, "_slot_nb", {})
+        self._slot_nb[slot] = p.shape[0]
+
+    def probes_select(self, slot):
+        self._chk(self._lib.sw_probes_select(self._h, slot), "sw_probes_select")
+        self._nb_uploaded = self._slot_nb[slot]
+
+    def kernel_stats(self, which):
+        ms = C.c_double(0.0)
+        cnt = C.c_int64(0)
+        self._chk(self._lib.sw_kernel_stats(self._h, which, C.byref(ms), C.byref(cnt)),
+                  "sw_kernel_stats")
+        return ms.value, int(cnt.value)
 
     def hutch_run(self, mode, level, tol, maxiter=1000):
         self._chk(self._lib.sw_hutch_run(self._h, mode, level, float(tol), int(maxiter)),

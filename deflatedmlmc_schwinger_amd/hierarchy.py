@@ -236,12 +236,43 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
 # ---------------------------------------------------------------------------------------
 # solver hierarchy (level-0 preconditioner only)
 # ---------------------------------------------------------------------------------------
+def smoother_weights(A, degree, seed=2024):
+    """Weights 1/theta_k of a degree-`degree` fixed polynomial smoother for A: theta_k are the
+    roots of the GMRES(degree) residual polynomial (harmonic Ritz values) of a random complex
+    right-hand side, Leja-ordered for stability.  x <- x + w_k (b - A x), k = 0..degree-1."""
+    import scipy.linalg as sla
+    if degree <= 0:
+        return np.zeros(0, dtype=np.complex128)
+    n = A.shape[0]
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    V = [b / np.linalg.norm(b)]
+    H = np.zeros((degree + 1, degree), dtype=np.complex128)
+    for j in range(degree):
+        w = A @ V[j]
+        for i in range(j + 1):
+            H[i, j] = np.vdot(V[i], w)
+            w = w - H[i, j] * V[i]
+        H[j + 1, j] = np.linalg.norm(w)
+        V.append(w / H[j + 1, j])
+    theta = list(sla.eig(H.conj().T @ H, H[:degree, :].conj().T)[0])
+    ordered = [max(theta, key=abs)]
+    theta.remove(ordered[0])
+    while theta:
+        nxt = max(theta, key=lambda t: np.prod([abs(t - o) for o in ordered]))
+        ordered.append(nxt)
+        theta.remove(nxt)
+    return 1.0 / np.array(ordered, dtype=np.complex128)
+
+
 DEFAULT_SOLVER_CFG = {
     # (aggregate edge in sites of the level above, test vectors per chirality) per coarsening
-    "coarsening": [(4, 8), (4, 8)],
+    "coarsening": [(4, 8), (2, 8)],
     # per level: (nu_pre, nu_post, kcycle)
-    "cycle": [(0, 3, 2), (0, 3, 0)],
-    "restart": 24,
+    "cycle": [(0, 7, 0), (0, 7, 0)],
+    # "richardson": fixed-polynomial smoother (no inner products); "mr": adaptive MR steps
+    "smoother": "richardson",
+    "restart": 8,
     "eig_tol": 1.0e-6,
 }
 

@@ -107,35 +107,51 @@ class MG:
         cfg = params.get("solver_cfg") if params else None
         want = True if params is None else params.get("use_solver_hierarchy", True)
         self._have_solver_hier = False
-        restart = 24
         if want and lat is not None:
-            cfg = dict(_hier.DEFAULT_SOLVER_CFG if cfg is None else cfg)
-            L = lat[0]
-            ok = True
-            Lf = L
-            for (agg, _) in cfg["coarsening"]:
-                ok = ok and (Lf % agg == 0) and (Lf // agg >= 1)
-                Lf //= max(agg, 1)
-            if ok:
-                t0 = time.time()
-                sh = _hier.solver_hierarchy(levels[0].A, L, cfg,
-                                            testvectors=params.get("solver_testvectors"))
-                nl = len(sh["A"])
-                eng.hier_begin(SOLVER_HID, nl)
-                eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
-                for i in range(nl - 1):
-                    if i > 0:
-                        eng.set_csr(SOLVER_HID, i, sh["A"][i])
-                    eng.set_transfer(SOLVER_HID, i, sh["P"][i])
-                    cyc = cfg["cycle"][i]
-                    eng.set_cycle(SOLVER_HID, i, cyc[0], cyc[1], cyc[2])
-                eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
-                eng.hier_end(SOLVER_HID)
-                self._have_solver_hier = True
-                self.solver_info = {"levels": [a.shape[0] for a in sh["A"]],
-                                    "setup_s": time.time() - t0, "cfg": cfg}
-                restart = int(cfg.get("restart", 24))
-        eng.set_solver(restart, SOLVER_HID if self._have_solver_hier else REF_HID)
+            self.upload_solver_hierarchy(cfg, params.get("solver_testvectors") if params else None)
+        else:
+            eng.set_solver(24, REF_HID)
+
+    def upload_solver_hierarchy(self, cfg=None, testvectors=None):
+        """(Re)build the level-0 preconditioner hierarchy from `cfg` and make it the solver."""
+        eng = self._need_engine()
+        lat = self.lattice
+        if lat is None:
+            raise Exception("the solver hierarchy needs a lattice operator at level 0")
+        cfg = dict(_hier.DEFAULT_SOLVER_CFG if cfg is None else cfg)
+        L = lat[0]
+        Lf = L
+        for (agg, _) in cfg["coarsening"]:
+            if agg < 1 or Lf % agg:
+                raise Exception("lattice extent %d not divisible by aggregate edge %d" % (Lf, agg))
+            Lf //= agg
+        t0 = time.time()
+        sh = _hier.solver_hierarchy(self.ml.levels[0].A, L, cfg, testvectors=testvectors)
+        nl = len(sh["A"])
+        eng.hier_begin(SOLVER_HID, nl)
+        eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
+        self.solver_hier = sh
+        self.solver_weights = []
+        for i in range(nl - 1):
+            if i > 0:
+                eng.set_csr(SOLVER_HID, i, sh["A"][i])
+            eng.set_transfer(SOLVER_HID, i, sh["P"][i])
+            cyc = cfg["cycle"][i]
+            eng.set_cycle(SOLVER_HID, i, cyc[0], cyc[1], cyc[2])
+            if cfg.get("smoother", "richardson") == "richardson":
+                wts = (_hier.smoother_weights(sh["A"][i], cyc[0]),
+                       _hier.smoother_weights(sh["A"][i], cyc[1]))
+                eng.set_smoother(SOLVER_HID, i, wts[0], wts[1])
+                self.solver_weights.append(wts)
+            else:
+                self.solver_weights.append(None)
+        eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
+        eng.hier_end(SOLVER_HID)
+        self._have_solver_hier = True
+        self.solver_testvectors = sh["tv"]
+        self.solver_info = {"levels": [a.shape[0] for a in sh["A"]],
+                            "setup_s": time.time() - t0, "cfg": cfg}
+        eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
 
     # ------------------------------------------------------------------------------------
     def _need_engine(self):

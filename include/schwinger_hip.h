@@ -30,7 +30,7 @@ extern "C" {
 
 #define SW_MAX_HIER 2
 #define SW_MAX_LEVELS 8
-#define SW_MAX_KRYLOV 48
+#define SW_MAX_KRYLOV 32
 #define SW_MAX_DEFL 64
 
 typedef struct sw_engine sw_engine;
@@ -64,6 +64,12 @@ int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense);
  * Stands in for lgmres(maxiter=smooth_iters) at multigrid.py:393-394,438-439 (parity is on
  * converged solves). */
 int sw_set_cycle(sw_engine* h, int hid, int level, int nu_pre, int nu_post, int kcycle);
+/* Replace the adaptive MR steps at `level` by a fixed polynomial smoother: n_pre / n_post
+ * Richardson steps x <- x + w_k (b - A x) with complex128 weights w_k (the inverse roots of a
+ * GMRES residual polynomial computed at setup).  One fused kernel per step, no inner products.
+ * n_pre = n_post = 0 returns to MR(nu) of sw_set_cycle. */
+int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w_pre, int n_post,
+                    const double* w_post);
 /* Mark the hierarchy complete (allocates level workspaces lazily). */
 int sw_hier_end(sw_engine* h, int hid);
 
@@ -109,7 +115,10 @@ int sw_hutch_batch(sw_engine* h, int mode, int level, int nb, const int8_t* prob
                    int maxiter, double* ests, int32_t* iters);
 /* Split form used when the probes are to be resident in HBM before timing starts:
  * upload -> run (asynchronous on the engine stream) -> sync -> fetch. */
-int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes);
+int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes);   /* slot 0 + select */
+/* Several batches resident at once (bench: all inputs in HBM before the timed region). */
+int sw_probes_upload_slot(sw_engine* h, int slot, int level, int nb, const int8_t* probes);
+int sw_probes_select(sw_engine* h, int slot);
 int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter);
 int sw_sync(sw_engine* h);
 int sw_hutch_fetch(sw_engine* h, double* ests, int32_t* iters);
@@ -125,6 +134,10 @@ int sw_bench_dirac(sw_engine* h, int hid, int level, int nb, int reps, double* m
 int sw_set_profiling(sw_engine* h, int on);
 int sw_timers(sw_engine* h, double t[8]);
 int sw_timers_reset(sw_engine* h);
+/* Accumulated HIP-event time and launch count of one kernel class since the last reset
+ * (profiling on): classes 0..7 as sw_timers, 8 = the level-0 Wilson stencil kernel alone. */
+#define SW_KCLASS_STENCIL 8
+int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);
 /* Kernel launches issued since the last reset (for launch-bound analysis). */
 int sw_launch_count(sw_engine* h, int64_t* n);
 

@@ -50,14 +50,37 @@ def fgmres_fixed(A, B, M, k):
     return X
 
 
-def cycle(As, Ps, cinv, cfg, level, B):
-    """cfg[l] = (nu_pre, nu_post, kcycle); B is [n, nb]."""
+def richardson(A, B, X, weights, from_zero):
+    """x <- x + w_k (B - A x) for the given complex weights."""
+    for k, w in enumerate(weights):
+        if from_zero and k == 0:
+            X = w * B
+        else:
+            X = X + w * (B - A @ X)
+    return X
+
+
+def cycle(As, Ps, cinv, cfg, level, B, weights=None):
+    """cfg[l] = (nu_pre, nu_post, kcycle); B is [n, nb].  weights[l] = (w_pre, w_post) selects the
+    fixed-polynomial smoother at level l (None: adaptive MR steps)."""
     last = len(As) - 1
     if level == last:
         return np.asarray(cinv) @ B
     nu_pre, nu_post, kc = cfg[level]
     A, P = As[level], Ps[level]
     R = P.conj().T
+    if weights is not None and weights[level] is not None:
+        w_pre, w_post = weights[level]
+        if len(w_pre):
+            X = richardson(A, B, None, w_pre, True)
+            Bc = R @ (B - A @ X)
+        else:
+            X = None
+            Bc = R @ B
+        sub = lambda v: cycle(As, Ps, cinv, cfg, level + 1, v, weights)   # noqa: E731
+        Xc = fgmres_fixed(As[level + 1], Bc, sub, kc) if (kc > 0 and level + 1 < last) else sub(Bc)
+        X = P @ Xc if X is None else X + P @ Xc
+        return richardson(A, B, X, w_post, False)
     if nu_pre > 0:
         X, res = mr_smooth(A, np.zeros_like(B), B.copy(), nu_pre)
         Bc = R @ res

@@ -127,6 +127,18 @@ def test_vcycle_matches_numpy_model(p16, p128):
             assert _relerr(X.T, ref) < 1e-10, "cycle from level %d" % level0
 
 
+def test_solver_cycle_polynomial_smoother_matches_numpy_model(p16, p128):
+    """the level-0 preconditioner cycle (fixed-polynomial smoother fused into the operator
+    kernels) against the NumPy model with the same weights."""
+    for p in (p16, p128):
+        sh = p.mg.solver_hier
+        cfg = [tuple(c) for c in sh["cfg"]["cycle"]]
+        B = _rand((sh["A"][0].shape[0], 3), 45)
+        ref = em.cycle(sh["A"], sh["P"], sh["coarsest_inv"], cfg, 0, B, weights=p.mg.solver_weights)
+        X = p.eng.vcycle(SOLVER_HID, 0, B.T.copy())
+        assert _relerr(X.T, ref) < 1e-10
+
+
 def test_solve_reaches_tolerance_and_matches_lu(p16, p128):
     for p, tol_x in ((p16, 1e-9), (p128, 1e-8)):
         n = p.A.shape[0]

@@ -1,0 +1,38 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/*.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from deflatedmlmc_schwinger_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "schwinger_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    names = declared_symbols()
+    assert len(names) >= 40
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # the Python binding lists the same set
+    assert sorted(engine.EXPORTED_SYMBOLS) == names
+
+
+def test_version_and_device_count(lib_built):
+    assert b"gfx950" in lib_built.sw_version()
+    assert engine.device_count() >= 0
+
+
+def test_create_without_gpu_reports_error(lib_built):
+    if engine.device_count() > 0:
+        return
+    h = ctypes.c_void_p()
+    assert lib_built.sw_create(ctypes.byref(h), 0) != 0
+    assert b"no HIP device" in lib_built.sw_last_error(None)

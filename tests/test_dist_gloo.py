@@ -1,0 +1,85 @@
+"""CPU: the N > 1 probe-sharding path with world_size 2 over gloo.  The GPU evaluator is
+replaced by an exact host evaluator (oracle LU on the 16^2 lattice); what is under test is the
+product's sharding / gathering / replay code (dist.py + stoch_trace.run_probe_loop)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_eval():
+    sys.path.insert(0, ROOT)
+    from deflatedmlmc_schwinger_amd import gateway, matrix
+    from oracle import ref_path as rp
+    p = gateway.set_params('schwinger16')
+    A = matrix.loadMatrix(p['matrix'], p['matrix_params'])
+    lu = rp.LUSolver(A)
+
+    def evaluate(probes):
+        e = np.array([rp.hutch_probe(x.astype(np.complex128), lu, None, None) for x in probes])
+        return e, np.full(len(e), 3), np.zeros(len(e), dtype=np.int64)
+    return A.shape[0], evaluate
+
+
+def _worker(rank, world, port, tol, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from deflatedmlmc_schwinger_amd import dist, stoch_trace
+    n, evaluate = _make_eval()
+    comm = dist.TorchComm()
+    assert comm.my_slice(10) == ((0, 5) if rank == 0 else (5, 10))
+    np.random.seed(123456)
+    out = stoch_trace.run_probe_loop(evaluate, n, tol, 100000, batch, comm=comm)
+    stats = comm.allreduce_stats(dist.local_stats(out["ests"][rank::world]))
+    q.put((rank, out["index"], complex(out["avg"]), float(out["dev"]), out["ests"].tolist(),
+           int(out["iters_fine"].sum()), stats.tolist(), int(np.random.randint(1 << 30))))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_probe_loop_equals_single_process():
+    sys.path.insert(0, ROOT)
+    from deflatedmlmc_schwinger_amd import dist, stoch_trace
+    n, evaluate = _make_eval()
+    tol = 6.0
+    np.random.seed(123456)
+    ref = stoch_trace.run_probe_loop(evaluate, n, tol, 100000, 16, comm=dist.Comm())
+    ref_next = int(np.random.randint(1 << 30))
+    assert ref["index"] >= 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tol, 8, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, idx, avg, dev, ests, its, stats, nxt in results:
+        assert idx == ref["index"]
+        assert avg == complex(ref["avg"]) and dev == float(ref["dev"])
+        assert np.array_equal(np.array(ests), ref["ests"])
+        assert its == int(ref["iters_fine"].sum())
+        assert nxt == ref_next                       # global stream left where 1 process leaves it
+        mean, std = dist.mean_and_population_std(stats)
+        assert abs(mean - ref["avg"]) < 1e-9 * abs(ref["avg"])
+        assert abs(std - ref["dev"]) < 1e-9 * ref["dev"]

@@ -46,6 +46,10 @@ struct EllOp {
   int* cols = nullptr;
   cplx* vals = nullptr;
   bool set = false;
+  // optional MFMA block-row form (square operators with n % 16 == 0 and dense-ish 16x4 blocks)
+  int bsr_KS = 0;
+  int* bsr_kcol = nullptr;   // [n/16][KS] first X row of each 4-column group
+  cplx* bsr_vals = nullptr;  // [n/16][KS][64] lane-packed
 };
 
 struct KrylovWS {
@@ -85,8 +89,6 @@ struct Hier {
   int nlevels = 0;
   Level lv[SW_MAX_LEVELS];
   EllOp cinv;
-  cplx* cinv_packed = nullptr;   // MFMA layout (n % 16 == 0)
-  int cinv_n = 0;
   bool ready = false;
 };
 
@@ -102,6 +104,7 @@ struct sw_engine {
   Hier hier[SW_MAX_HIER];
   int restart = 24;
   int solver_hid = 0;
+  bool use_mfma = true;
   // deflation
   int kd = 0;
   cplx* U = nullptr;  // [n0][kd] internal row order
@@ -337,12 +340,91 @@ static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_
   return 0;
 }
 
+// MFMA block-row form of a square CSR operator in natural order (level >= 1 operators and the
+// dense inverse).  Built only when at least `min_fill` of the packed 16x4 groups is non-zero.
+static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, const int32_t* indices,
+                     const std::complex<double>* data, double min_fill) {
+  op.bsr_KS = 0;
+  if (n % 16) return 0;
+  const int RT = n / 16;
+  std::vector<std::vector<int>> groups(RT);
+  size_t total = 0;
+  int KS = 0;
+  for (int rt = 0; rt < RT; ++rt) {
+    std::vector<int>& g = groups[rt];
+    for (int r = rt * 16; r < rt * 16 + 16; ++r)
+      for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) g.push_back(indices[q] >> 2);
+    std::sort(g.begin(), g.end());
+    g.erase(std::unique(g.begin(), g.end()), g.end());
+    KS = std::max(KS, (int)g.size());
+    total += g.size();
+  }
+  if (KS == 0) return 0;
+  KS += KS & 1;   // the kernel's two-stage pipeline wants an even number of k-steps
+  const double fill = (double)indptr[n] / ((double)RT * KS * 64.0);
+  if (fill < min_fill) return 0;
+  std::vector<int> kcol((size_t)RT * KS, 0);
+  std::vector<std::complex<double>> pk((size_t)RT * KS * 64, std::complex<double>(0, 0));
+  for (int rt = 0; rt < RT; ++rt) {
+    const std::vector<int>& g = groups[rt];
+    for (size_t k = 0; k < g.size(); ++k) kcol[(size_t)rt * KS + k] = g[k] * 4;
+    for (int i = 0; i < 16; ++i) {
+      const int r = rt * 16 + i;
+      for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+        const int c = indices[q];
+        const size_t k = std::lower_bound(g.begin(), g.end(), c >> 2) - g.begin();
+        const int lane = i + 16 * (c & 3);
+        pk[((size_t)rt * KS + k) * 64 + lane] += data[q];
+      }
+    }
+  }
+  SWCHK(upload(h, &op.bsr_kcol, kcol.data(), kcol.size()));
+  SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, pk.data(), pk.size()));
+  op.bsr_KS = KS;
+  return 0;
+}
+
+static int free_op(sw_engine* h, EllOp& op) {
+  SWCHK(dev_free(h, op.cols));
+  SWCHK(dev_free(h, op.vals));
+  SWCHK(dev_free(h, op.bsr_kcol));
+  SWCHK(dev_free(h, op.bsr_vals));
+  op = EllOp();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel launch wrappers
 // ---------------------------------------------------------------------------------------------
+static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B, cplx* Y,
+                      int nbp, int cat, cplx w) {
+  const int RT = op.nrows / 16;
+  dim3 grid((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
+  LaunchScope ls(h, cat);
+  const double* Xr = (const double*)X;
+  const double* Br = (const double*)B;
+  double* Yr = (double*)Y;
+  if (mode == 0)
+    hipLaunchKernelGGL((swk::k_bsr_mfma<0>), grid, dim3(SW_BLOCK), 0, h->stream,
+                       (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr,
+                       2 * nbp, nbp, w);
+  else if (mode == 1)
+    hipLaunchKernelGGL((swk::k_bsr_mfma<1>), grid, dim3(SW_BLOCK), 0, h->stream,
+                       (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr,
+                       2 * nbp, nbp, w);
+  else
+    hipLaunchKernelGGL((swk::k_bsr_mfma<3>), grid, dim3(SW_BLOCK), 0, h->stream,
+                       (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr,
+                       2 * nbp, nbp, w);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
 static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B,
                       cplx* Y, int nbp, int cat, cplx w = cplx{0.0, 0.0}) {
   if (!op.set) return sw_fail(h, "operator not set");
+  if (op.bsr_KS > 0 && (mode == 0 || mode == 1 || mode == 3) && h->use_mfma)
+    return launch_bsr(h, op, mode, X, B, Y, nbp, cat, w);
   dim3 grid((op.ngroups + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
   LaunchScope ls(h, cat);
 #define ELL_CASE(GG)                                                                            \
@@ -374,18 +456,9 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   return 0;
 }
 
-// Y = coarsest_inv X : fp64 MFMA kernel when the size allows, grouped-ELL otherwise
+// Y = coarsest_inv X : fp64 MFMA block-row kernel when the size allows, grouped-ELL otherwise
 static int apply_coarsest(sw_engine* h, Hier& H, const cplx* X, cplx* Y, int nbp) {
   if (!H.cinv.set) return sw_fail(h, "coarsest inverse not set");
-  if (H.cinv_packed && (nbp % 16) == 0) {
-    const int n = H.cinv_n;
-    dim3 grid((n / 16 + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, (2 * nbp) / 32);
-    LaunchScope ls(h, T_COARSEST);
-    hipLaunchKernelGGL(swk::k_dense_mfma, grid, dim3(SW_BLOCK), 0, h->stream,
-                       (const cplx*)H.cinv_packed, n, (const double*)X, (double*)Y, 2 * nbp);
-    KLAUNCH_CHECK();
-    return 0;
-  }
   return launch_ell(h, H.cinv, 0, X, nullptr, Y, nbp, T_COARSEST);
 }
 
@@ -947,9 +1020,9 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
   for (int l = 0; l < SW_MAX_LEVELS; ++l) {
     Level& lv = H.lv[l];
     SWCHK(dev_free(h, lv.U1)); SWCHK(dev_free(h, lv.U2));
-    SWCHK(dev_free(h, lv.A.cols)); SWCHK(dev_free(h, lv.A.vals));
-    SWCHK(dev_free(h, lv.P.cols)); SWCHK(dev_free(h, lv.P.vals));
-    SWCHK(dev_free(h, lv.R.cols)); SWCHK(dev_free(h, lv.R.vals));
+    SWCHK(free_op(h, lv.A));
+    SWCHK(free_op(h, lv.P));
+    SWCHK(free_op(h, lv.R));
     SWCHK(dev_free(h, lv.rowmap));
     SWCHK(dev_free(h, lv.b)); SWCHK(dev_free(h, lv.x)); SWCHK(dev_free(h, lv.r));
     SWCHK(dev_free(h, lv.t));
@@ -957,10 +1030,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(free_krylov(h, lv.sws));
     lv = Level();
   }
-  SWCHK(dev_free(h, H.cinv.cols)); SWCHK(dev_free(h, H.cinv.vals));
-  SWCHK(dev_free(h, H.cinv_packed));
-  H.cinv_packed = nullptr;
-  H.cinv = EllOp();
+  SWCHK(free_op(h, H.cinv));
   H.nlevels = nlevels;
   H.ready = false;
   return 0;
@@ -1004,7 +1074,9 @@ int sw_set_csr(sw_engine* h, int hid, int level, int n, const int64_t* indptr,
   if (lv.n && lv.n != n) return sw_fail(h, "sw_set_csr: level %d already has n=%d", level, lv.n);
   lv.n = n;
   std::vector<int> none;
-  return build_ell(h, lv.A, n, n, indptr, indices, (const std::complex<double>*)data, none, none);
+  SWCHK(free_op(h, lv.A));
+  SWCHK(build_ell(h, lv.A, n, n, indptr, indices, (const std::complex<double>*)data, none, none));
+  return build_bsr(h, lv.A, n, indptr, indices, (const std::complex<double>*)data, 0.6);
 }
 
 int sw_set_transfer(sw_engine* h, int hid, int level, int n_f, int n_c, const int64_t* indptr,
@@ -1072,6 +1144,7 @@ int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense) {
       hc[(size_t)gi * n + k] = k;
       for (int g = 0; g < G; ++g) hv[((size_t)gi * n + k) * G + g] = M[(size_t)(gi * G + g) * n + k];
     }
+  SWCHK(free_op(h, H.cinv));
   EllOp& op = H.cinv;
   op.nrows = op.ncols = n;
   op.K = n;
@@ -1080,18 +1153,21 @@ int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense) {
   SWCHK(upload(h, &op.cols, hc.data(), hc.size()));
   SWCHK(upload(h, (std::complex<double>**)&op.vals, hv.data(), hv.size()));
   op.set = true;
-  SWCHK(dev_free(h, H.cinv_packed));
-  H.cinv_packed = nullptr;
-  H.cinv_n = n;
   if (n % 16 == 0) {
+    // dense -> MFMA block-row form: every 4-column group of every 16-row tile
     const int KS = n / 4, RT = n / 16;
+    std::vector<int> kcol((size_t)RT * KS);
     std::vector<std::complex<double>> pk((size_t)RT * KS * 64);
     for (int rt = 0; rt < RT; ++rt)
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks) {
+        kcol[(size_t)rt * KS + ks] = ks * 4;
         for (int lane = 0; lane < 64; ++lane)
           pk[((size_t)rt * KS + ks) * 64 + lane] =
               M[(size_t)(rt * 16 + (lane & 15)) * n + ks * 4 + (lane >> 4)];
-    SWCHK(upload(h, (std::complex<double>**)&H.cinv_packed, pk.data(), pk.size()));
+      }
+    SWCHK(upload(h, &op.bsr_kcol, kcol.data(), kcol.size()));
+    SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, pk.data(), pk.size()));
+    op.bsr_KS = KS;
   }
   return 0;
 }
@@ -1150,6 +1226,15 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid) {
   return 0;
 }
 
+int sw_set_option(sw_engine* h, const char* name, double value) {
+  if (!h || !name) return 1;
+  if (std::strcmp(name, "use_mfma") == 0) {
+    h->use_mfma = value != 0.0;
+    return 0;
+  }
+  return sw_fail(h, "unknown option %s", name);
+}
+
 int sw_set_deflation(sw_engine* h, int k, const double* U) {
   SWCHK(check_hier(h, 0, 0, false));
   if (k < 0 || k > SW_MAX_DEFL) return sw_fail(h, "deflation rank %d out of [0,%d]", k, SW_MAX_DEFL);
@@ -1199,9 +1284,7 @@ int sw_set_rhsmap(sw_engine* h, int level, int n, const int64_t* indptr, const i
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[0].lv[level];
   if (lv.n != n) return sw_fail(h, "rhs map size %d != level size %d", n, lv.n);
-  SWCHK(dev_free(h, h->rhsmap[level].cols));
-  SWCHK(dev_free(h, h->rhsmap[level].vals));
-  h->rhsmap[level] = EllOp();
+  SWCHK(free_op(h, h->rhsmap[level]));
   std::vector<int> rows_int;
   if (!lv.h_rowmap.empty()) {
     rows_int.resize(n);

@@ -203,49 +203,96 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 }
 
 // ------------------------------------------------------------------------------------------
-// Dense coarsest-level inverse (multigrid.py:413-416) on the fp64 matrix cores:
-//   Y[n][nbp] = M[n][n] * X[n][nbp]   (complex128)
+// Block-row operator on the fp64 matrix cores: the dense coarsest-level inverse
+// (multigrid.py:413-416) and block-structured coarse operators.
+//   Y[n][nbp] (op)= A[n][n] * X[n][nbp]   (complex128, A given per 16-row tile as a list of
+//   4-column groups: "k-steps")
 // v_mfma_f64_16x16x4_f64:  D(16x16) += A(16x4) B(4x16),  lane l holds A[l&15][l>>4],
 // B[l>>4][l&15] and D[(l>>4)+4r][l&15], r<4 (cdna_hip_programming.md section 3).
 // X and Y are used as REAL [n][2*nbp] matrices (re/im interleaved along the row), so one
-// 16-column MFMA tile covers 8 probes.  Two accumulators per tile: D1 = Re(M) X'', D2 = Im(M) X'';
+// 16-column MFMA tile covers 8 probes.  Two accumulators per tile: D1 = Re(A) X'', D2 = Im(A) X'';
 //   Y''[i][2j] = D1[i][2j] - D2[i][2j+1],   Y''[i][2j+1] = D1[i][2j+1] + D2[i][2j]
-// i.e. one neighbour-lane exchange in the epilogue.  M is pre-packed at upload time so every
-// k-step of a 16-row tile is one coalesced 1-KiB read:  Mp[(rt*KS + ks)*64 + lane] =
-// M[rt*16 + (lane&15)][ks*4 + (lane>>4)].   One wave = 16 rows x 32 real columns (16 probes).
+// i.e. one neighbour-lane exchange in the epilogue.  A is pre-packed at upload time so every
+// k-step of a tile is one coalesced 1-KiB read:  Ap[(rt*KS + ks)*64 + lane] =
+// A[rt*16 + (lane&15)][kcol[rt*KS+ks] + (lane>>4)].
+// One wave = one 16-row tile x 64 probes = 8 MFMA column tiles (16 accumulators).
+// MODE 0: Y = A X   MODE 1: Y = B - A X   MODE 3: Y = X + w (B - A X)
 // ------------------------------------------------------------------------------------------
 typedef double sw_double4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(SW_BLOCK) void k_dense_mfma(const cplx* __restrict__ Mp, int n,
-                                                         const double* __restrict__ Xr,
-                                                         double* __restrict__ Yr, int ld) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rt = blockIdx.x * SW_WAVES_PER_BLOCK + wave;
-  if (rt * 16 >= n) return;
-  const int c0 = blockIdx.y * 32;
-  const int KS = n / 4;
-  const cplx* a = Mp + (size_t)rt * KS * 64 + lane;
+template <int MODE>
+__global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ Ap,
+                                                       const int* __restrict__ kcol, int KS,
+                                                       int RT, const double* __restrict__ Xr,
+                                                       const double* __restrict__ Br,
+                                                       double* __restrict__ Yr, int ld, int nbp,
+                                                       cplx w) {
+  // the 4 waves of a workgroup take 4 consecutive row tiles and the SAME 64-probe chunk, so
+  // the X rows they share (all of them for a dense operator, the common neighbours for a
+  // block stencil) are served once from L2 and then from the CU's L1
+  const int lane = threadIdx.x & 63;
+  const int rt = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (rt >= RT) return;
+  const int c0 = blockIdx.y * 128;                  // first real column of this chunk
+  const cplx* a = Ap + (size_t)rt * KS * 64 + lane;
+  const int* kc = kcol + (size_t)rt * KS;           // wave-uniform -> scalar loads
   const double* b = Xr + (size_t)(lane >> 4) * ld + c0 + (lane & 15);
-  sw_double4 re0 = {0.0, 0.0, 0.0, 0.0}, im0 = re0, re1 = re0, im1 = re0;
-#pragma unroll 4
-  for (int ks = 0; ks < KS; ++ks) {
-    const cplx m = a[(size_t)ks * 64];
-    const double x0 = b[(size_t)ks * 4 * ld];
-    const double x1 = b[(size_t)ks * 4 * ld + 16];
-    re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.x, x0, re0, 0, 0, 0);
-    im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.y, x0, im0, 0, 0, 0);
-    re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.x, x1, re1, 0, 0, 0);
-    im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m.y, x1, im1, 0, 0, 0);
+  sw_double4 re[8], im[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    re[t] = sw_double4{0.0, 0.0, 0.0, 0.0};
+    im[t] = re[t];
   }
+  // Two named register stages (KS is even): the loads of k-step ks+2 are issued right behind
+  // the 16 MFMAs of k-step ks and have a whole k-step of matrix work to land; the
+  // sched_barriers keep hipcc from sinking the loads below the next MFMA block.
+#define SW_BSR_LOAD(M_, X_, KSI)                               \
+  {                                                            \
+    M_ = a[(size_t)(KSI) * 64];                                \
+    const double* bk_ = b + (size_t)kc[(KSI)] * ld;            \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) X_[t] = bk_[t * 16]; \
+  }
+#define SW_BSR_MFMA(M_, X_)                                                        \
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                  \
+    re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.x, X_[t], re[t], 0, 0, 0);     \
+    im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.y, X_[t], im[t], 0, 0, 0);     \
+  }
+  cplx m0, m1;
+  double x0[8], x1[8];
+  SW_BSR_LOAD(m0, x0, 0);
+  SW_BSR_LOAD(m1, x1, 1);
+  for (int ks = 0; ks < KS; ks += 2) {
+    const int k2 = (ks + 2 < KS) ? ks + 2 : ks;
+    const int k3 = (ks + 3 < KS) ? ks + 3 : ks + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    SW_BSR_MFMA(m0, x0);
+    __builtin_amdgcn_sched_barrier(0);
+    SW_BSR_LOAD(m0, x0, k2);
+    __builtin_amdgcn_sched_barrier(0);
+    SW_BSR_MFMA(m1, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    SW_BSR_LOAD(m1, x1, k3);
+  }
+#undef SW_BSR_LOAD
+#undef SW_BSR_MFMA
   const int c = lane & 15;
   const bool odd = (c & 1) != 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const size_t row = (size_t)rt * 16 + (lane >> 4) + 4 * r;
-    const double s0 = __shfl_xor(im0[r], 1);
-    const double s1 = __shfl_xor(im1[r], 1);
-    Yr[row * ld + c0 + c] = odd ? re0[r] + s0 : re0[r] - s0;
-    Yr[row * ld + c0 + 16 + c] = odd ? re1[r] + s1 : re1[r] - s1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const double s = __shfl_xor(im[t][r], 1);
+      double y = odd ? re[t][r] + s : re[t][r] - s;
+      const size_t off = row * ld + c0 + t * 16 + c;
+      if (MODE == 1) y = Br[off] - y;
+      if (MODE == 3) {
+        const double tt = Br[off] - y;
+        const double tp = __shfl_xor(tt, 1);
+        y = Xr[off] + w.x * tt + (odd ? w.y * tp : -w.y * tp);
+      }
+      Yr[off] = y;
+    }
   }
 }
 

@@ -67,6 +67,7 @@ def load_library():
     sig("sw_set_perm", i32, vp, i32, i64)
     sig("sw_set_rhsmap", i32, vp, i32, i32, vp, vp, vp)
     sig("sw_set_solver", i32, vp, i32, i32)
+    sig("sw_set_option", i32, vp, C.c_char_p, dbl)
     sig("sw_apply_dirac", i32, vp, i32, i32, i32, vp, vp)
     sig("sw_restrict", i32, vp, i32, i32, i32, vp, vp)
     sig("sw_prolong", i32, vp, i32, i32, i32, vp, vp)
@@ -98,7 +99,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_set_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver",
+    "sw_set_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -227,6 +228,9 @@ class Engine:
 
     def set_solver(self, restart=24, solver_hid=0):
         self._chk(self._lib.sw_set_solver(self._h, restart, solver_hid), "sw_set_solver")
+
+    def set_option(self, name, value):
+        self._chk(self._lib.sw_set_option(self._h, name.encode(), float(value)), "sw_set_option")
 
     # -- building blocks -------------------------------------------------------------------
     def _io(self, X, n_in):

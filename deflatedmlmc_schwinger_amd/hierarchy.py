@@ -277,26 +277,34 @@ DEFAULT_SOLVER_CFG = {
 }
 
 
-def _site_prolongator(Al, Lf, hd, agg, nvec, tv):
-    """P for 2-D aggregates: rows ordered [half][y][x][k<hd] on an Lf x Lf lattice, columns
-    ordered [half][yc][xc][v<nvec]; each (aggregate, half) block is orthonormalised by QR."""
+def _site_prolongator(Al, Lf, hd, agg, nvec, tv, fine_level):
+    """P for 2-D site aggregates with a chirality split.
+
+    Rows: level 0 uses the reference order idx = half*V + site; coarse levels are ordered
+    site-major, idx = (site*2 + half)*hd + k, so that the 2*hd dofs of a site are contiguous
+    (one 16-row MFMA tile per site when 2*hd == 16).  Columns: (csite*2 + half)*nvec + v.
+    Each (aggregate, half) block is orthonormalised by QR."""
     n = Al.shape[0]
     Lc = Lf // agg
     idx = np.arange(n)
-    half = idx // (n // 2)
-    rem = idx % (n // 2)
-    site = rem // hd
+    if fine_level:
+        half = idx // (n // 2)
+        site = idx % (n // 2)
+    else:
+        site = idx // (2 * hd)
+        half = (idx // hd) % 2
     x, y = site % Lf, site // Lf
-    block = half * (Lc * Lc) + (y // agg) * Lc + (x // agg)
+    block = ((y // agg) * Lc + (x // agg)) * 2 + half
     order = np.argsort(block, kind="stable")
-    rows_per_block = n // (2 * Lc * Lc)
-    rows_sorted = order.reshape(2 * Lc * Lc, rows_per_block)
+    nblocks = 2 * Lc * Lc
+    rows_per_block = n // nblocks
+    rows_sorted = order.reshape(nblocks, rows_per_block)
     M = np.asarray(tv)[rows_sorted, :nvec]            # [blocks, rows, nvec]
     Q, _ = np.linalg.qr(M)
     rr = np.repeat(rows_sorted[:, :, None], nvec, axis=2)
-    cc = (np.arange(2 * Lc * Lc)[:, None, None] * nvec + np.arange(nvec)[None, None, :]
+    cc = (np.arange(nblocks)[:, None, None] * nvec + np.arange(nvec)[None, None, :]
           + np.zeros((1, rows_per_block, 1), dtype=np.int64))
-    return sp.csr_matrix((Q.ravel(), (rr.ravel(), cc.ravel())), shape=(n, 2 * Lc * Lc * nvec))
+    return sp.csr_matrix((Q.ravel(), (rr.ravel(), cc.ravel())), shape=(n, nblocks * nvec))
 
 
 def solver_hierarchy(A0, L, cfg=None, testvectors=None):
@@ -315,7 +323,7 @@ def solver_hierarchy(A0, L, cfg=None, testvectors=None):
             _, tv = spla.eigs(sp.csc_matrix(As[-1]), k=nvec, which="LM", sigma=0.0,
                               tol=cfg.get("eig_tol", 1e-6))
         tvs.append(tv)
-        P = _site_prolongator(As[-1], Lf, hd, agg, nvec, tv)
+        P = _site_prolongator(As[-1], Lf, hd, agg, nvec, tv, lvl == 0)
         Ac = sp.csr_matrix(P.conjugate().transpose() @ As[-1] @ P)
         Ps.append(P)
         As.append(Ac)

@@ -85,6 +85,10 @@ int sw_set_rhsmap(sw_engine* h, int level, int n, const int64_t* indptr, const i
  * precondition level-0 solves (0 or 1). */
 int sw_set_solver(sw_engine* h, int restart, int solver_hid);
 
+/* Engine switches for A/B measurements: "use_mfma" (1/0): fp64-MFMA block-row kernels for the
+ * dense coarsest inverse and block-structured coarse operators vs the grouped-ELL kernels. */
+int sw_set_option(sw_engine* h, const char* name, double value);
+
 /* ---- building blocks (host buffers, reference ordering) -------------------------------- */
 /* Y = A_level X.  Replaces MG.matvec (multigrid.py:552-557) and the residual SpMVs at
  * multigrid.py:388,402,433.  X,Y: complex128[nb*n]. */

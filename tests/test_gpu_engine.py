@@ -263,3 +263,47 @@ def test_timers_and_launch_count(p16):
 def test_bench_dirac_runs(p128):
     ms = p128.eng.bench_dirac(REF_HID, 0, 256, 5)
     assert 0 < ms < 50
+
+
+EXACT_128 = -8.748242701374695 + 50.215154098005584j      # gateway.py:100-104
+
+
+def test_full_mlmc_flow_128_within_reported_error(capsys):
+    """BASELINE config 3 / G202: the drop-in mlmc() on schwinger128 with the shipped preset;
+    the trace must agree with the reference's exact value within the estimator's own error."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    res = stoch_trace.mlmc(A, tp)
+    capsys.readouterr()
+    assert res['nr_levels'] == 4
+    err2 = 0.0
+    for i in (0, 2):
+        r = res['results'][i]
+        assert r['nr_ests'] >= 5
+        err2 += r['ests_dev'] ** 2 / (r['nr_ests'] + 1)
+    assert res['results'][1]['nr_ests'] == 0            # skipped level
+    assert res['results'][3]['nr_ests'] == 1            # direct coarsest term
+    err = np.sqrt(err2)
+    assert abs(res['trace'] - EXACT_128) < 4.0 * err + 1e-9, (res['trace'], err)
+    # and the tolerance request itself (1e-2 relative on the rough trace) was met statistically
+    assert err < 2e-2 * abs(EXACT_128)
+    assert res['total_complexity'] > 0
+
+
+def test_full_deflated_hutchinson_flow_128_within_reported_error(capsys):
+    """G102: deflated Hutchinson, looser tolerance so the run stays short."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    params['trace_tol'] = 5.0e-2
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "hutchinson")
+    res = stoch_trace.hutchinson(A, tp)
+    capsys.readouterr()
+    n = res['nr_ests'] + 1
+    err = res['std_dev'] / np.sqrt(n)
+    assert abs(res['trace'] - EXACT_128) < 4.0 * err
+    assert res['function_iters'] >= n

@@ -43,6 +43,7 @@ def main():
             print(json.dumps({"cfg": cfg, "error": repr(e)}), flush=True)
             continue
         last_key, tv = key, mg.solver_testvectors
+        eng.set_option("use_mfma", float(cfg.get("use_mfma", 1)))
         t_setup = time.time() - t0
         eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
         eng.sync()

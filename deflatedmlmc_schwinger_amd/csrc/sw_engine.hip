@@ -105,6 +105,7 @@ struct sw_engine {
   int restart = 24;
   int solver_hid = 0;
   bool use_mfma = true;
+  int mfma_tiles = 4;
   // deflation
   int kd = 0;
   cplx* U = nullptr;  // [n0][kd] internal row order
@@ -399,23 +400,26 @@ static int free_op(sw_engine* h, EllOp& op) {
 static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B, cplx* Y,
                       int nbp, int cat, cplx w) {
   const int RT = op.nrows / 16;
-  dim3 grid((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
+  const int NT = h->mfma_tiles;   // MFMA column tiles per wave (8 probes each)
+  dim3 grid((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, (2 * nbp) / (16 * NT));
   LaunchScope ls(h, cat);
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
-  if (mode == 0)
-    hipLaunchKernelGGL((swk::k_bsr_mfma<0>), grid, dim3(SW_BLOCK), 0, h->stream,
-                       (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr,
-                       2 * nbp, nbp, w);
-  else if (mode == 1)
-    hipLaunchKernelGGL((swk::k_bsr_mfma<1>), grid, dim3(SW_BLOCK), 0, h->stream,
-                       (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr,
-                       2 * nbp, nbp, w);
-  else
-    hipLaunchKernelGGL((swk::k_bsr_mfma<3>), grid, dim3(SW_BLOCK), 0, h->stream,
-                       (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr,
-                       2 * nbp, nbp, w);
+#define BSR_LAUNCH(MD, NTT)                                                                     \
+  hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT>), grid, dim3(SW_BLOCK), 0, h->stream,            \
+                     (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr, \
+                     2 * nbp, nbp, w)
+  if (NT == 8) {
+    if (mode == 0) BSR_LAUNCH(0, 8);
+    else if (mode == 1) BSR_LAUNCH(1, 8);
+    else BSR_LAUNCH(3, 8);
+  } else {
+    if (mode == 0) BSR_LAUNCH(0, 4);
+    else if (mode == 1) BSR_LAUNCH(1, 4);
+    else BSR_LAUNCH(3, 4);
+  }
+#undef BSR_LAUNCH
   KLAUNCH_CHECK();
   return 0;
 }
@@ -1230,6 +1234,11 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (!h || !name) return 1;
   if (std::strcmp(name, "use_mfma") == 0) {
     h->use_mfma = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "mfma_tiles") == 0) {
+    if (value != 4.0 && value != 8.0) return sw_fail(h, "mfma_tiles must be 4 or 8");
+    h->mfma_tiles = (int)value;
     return 0;
   }
   return sw_fail(h, "unknown option %s", name);

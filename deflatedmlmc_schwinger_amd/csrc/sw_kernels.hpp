@@ -215,12 +215,15 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 // i.e. one neighbour-lane exchange in the epilogue.  A is pre-packed at upload time so every
 // k-step of a tile is one coalesced 1-KiB read:  Ap[(rt*KS + ks)*64 + lane] =
 // A[rt*16 + (lane&15)][kcol[rt*KS+ks] + (lane>>4)].
-// One wave = one 16-row tile x 64 probes = 8 MFMA column tiles (16 accumulators).
+// One wave = one 16-row tile x NT MFMA column tiles (8 probes each): NT = 8 keeps 16
+// accumulators (one wave per SIMD), NT = 4 halves the registers (two waves per SIMD: the pure
+// issue rate of v_mfma_f64_16x16x4 is 36 TF/s at one wave/SIMD and 47 TF/s at two,
+// tools/mfma_f64_rate.hip).
 // MODE 0: Y = A X   MODE 1: Y = B - A X   MODE 3: Y = X + w (B - A X)
 // ------------------------------------------------------------------------------------------
 typedef double sw_double4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+template <int MODE, int NT>
 __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ Ap,
                                                        const int* __restrict__ kcol, int KS,
                                                        int RT, const double* __restrict__ Xr,
@@ -233,13 +236,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int rt = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (rt >= RT) return;
-  const int c0 = blockIdx.y * 128;                  // first real column of this chunk
+  const int c0 = blockIdx.y * (16 * NT);            // first real column of this chunk
   const cplx* a = Ap + (size_t)rt * KS * 64 + lane;
   const int* kc = kcol + (size_t)rt * KS;           // wave-uniform -> scalar loads
   const double* b = Xr + (size_t)(lane >> 4) * ld + c0 + (lane & 15);
-  sw_double4 re[8], im[8];
+  sw_double4 re[NT], im[NT];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < NT; ++t) {
     re[t] = sw_double4{0.0, 0.0, 0.0, 0.0};
     im[t] = re[t];
   }
@@ -250,15 +253,15 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   {                                                            \
     M_ = a[(size_t)(KSI) * 64];                                \
     const double* bk_ = b + (size_t)kc[(KSI)] * ld;            \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t) X_[t] = bk_[t * 16]; \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) X_[t] = bk_[t * 16]; \
   }
 #define SW_BSR_MFMA(M_, X_)                                                        \
-  _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                  \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                 \
     re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.x, X_[t], re[t], 0, 0, 0);     \
     im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.y, X_[t], im[t], 0, 0, 0);     \
   }
   cplx m0, m1;
-  double x0[8], x1[8];
+  double x0[NT], x1[NT];
   SW_BSR_LOAD(m0, x0, 0);
   SW_BSR_LOAD(m1, x1, 1);
   for (int ks = 0; ks < KS; ks += 2) {
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   for (int r = 0; r < 4; ++r) {
     const size_t row = (size_t)rt * 16 + (lane >> 4) + 4 * r;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const double s = __shfl_xor(im[t][r], 1);
       double y = odd ? re[t][r] + s : re[t][r] - s;
       const size_t off = row * ld + c0 + t * 16 + c;

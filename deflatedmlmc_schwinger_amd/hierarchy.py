@@ -272,7 +272,7 @@ DEFAULT_SOLVER_CFG = {
     "cycle": [(0, 7, 0), (0, 7, 0)],
     # "richardson": fixed-polynomial smoother (no inner products); "mr": adaptive MR steps
     "smoother": "richardson",
-    "restart": 8,
+    "restart": 6,
     "eig_tol": 1.0e-6,
 }
 

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (kernel stats + PMC passes) of tools/profile_round.sh into the small
+text/JSON summaries that are committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    name = name.replace("HIP_vector_type<double, 2u>", "cplx")
+    return name.split("(")[0].replace("void ", "")[:70]
+
+
+def main(out):
+    lines = []
+    stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        lines.append("rocprofv3 --kernel-trace --stats  (bench.py --steps 4 --warmup 1)")
+        lines.append("%-72s %7s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
+        for r in rows[:24]:
+            lines.append("%-72s %7d %12.3f %10.2f %6.2f" % (
+                short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
+                float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+        lines.append("total kernel time %.1f ms" % (tot / 1e6))
+    pmc = {}
+    for key, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        files = glob.glob(os.path.join(out, key, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(files[0])):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            a = acc.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        pmc[counter] = acc
+    summary = {}
+    if pmc:
+        lines.append("")
+        lines.append("PMC passes (separate runs): per-launch averages; FETCH_SIZE/WRITE_SIZE are in KiB;")
+        lines.append("FETCH_SIZE is doubled for 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM)")
+        names = sorted(set(list(pmc.get("FETCH_SIZE", {})) + list(pmc.get("WRITE_SIZE", {}))))
+        lines.append("%-72s %12s %12s %12s" % ("kernel", "fetch_MB(x2)", "write_MB", "hbm_MB"))
+        for k in names:
+            f = pmc.get("FETCH_SIZE", {}).get(k)
+            w = pmc.get("WRITE_SIZE", {}).get(k)
+            fmb = 2.0 * f[1] / f[0] * 1024 / 1e6 if f else float("nan")
+            wmb = w[1] / w[0] * 1024 / 1e6 if w else float("nan")
+            lines.append("%-72s %12.2f %12.2f %12.2f" % (k, fmb, wmb, fmb + wmb))
+            if "k_stencil<0>" in k:
+                summary["hbm_bytes_per_launch"] = (fmb + wmb) * 1e6
+                summary["fetch_bytes_per_launch_corrected"] = fmb * 1e6
+                summary["write_bytes_per_launch"] = wmb * 1e6
+    text = "\n".join(lines)
+    open(os.path.join(out, "summary.txt"), "w").write(text + "\n")
+    if summary:
+        summary["note"] = ("k_stencil<0> averages over all launches of one bench step; FETCH_SIZE "
+                           "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)")
+        json.dump(summary, open(os.path.join(out, "stencil_pmc.json"), "w"), indent=1)
+    print(text)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -38,8 +38,15 @@ static int sw_fail(sw_engine* h, const char* fmt, ...);
     if (rc_ != 0) return rc_;   \
   } while (0)
 
-enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER, T_STENCIL, T_NCAT };
-// T_STENCIL is reported inside the mvm bucket by sw_timers and separately by sw_kernel_stats
+enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER,
+                T_STENCIL,      // k_stencil<0>  Y = A X
+                T_STENCIL_RES,  // k_stencil<1>  Y = B - A X
+                T_STENCIL_SM,   // k_stencil<2>  Y = X + w (B - A X)
+                T_MFMA_DENSE,   // k_bsr_mfma on the dense coarsest inverse
+                T_MFMA_OP,      // k_bsr_mfma on a block-structured level operator
+                T_NCAT };
+// classes >= T_STENCIL are folded into the mvm / coarsest buckets by sw_timers and reported
+// separately by sw_kernel_stats
 
 struct EllOp {
   int nrows = 0, ncols = 0, K = 0, G = 1, ngroups = 0;
@@ -106,6 +113,10 @@ struct sw_engine {
   int solver_hid = 0;
   bool use_mfma = true;
   int mfma_tiles = 4;
+  // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
+  // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
+  int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
+  bool lazy_sync = true;
   // deflation
   int kd = 0;
   cplx* U = nullptr;  // [n0][kd] internal row order
@@ -402,7 +413,7 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   const int RT = op.nrows / 16;
   const int NT = h->mfma_tiles;   // MFMA column tiles per wave (8 probes each)
   dim3 grid((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, (2 * nbp) / (16 * NT));
-  LaunchScope ls(h, cat);
+  LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE : (cat == T_MVM ? T_MFMA_OP : cat));
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
@@ -488,7 +499,7 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     const int waves = V / a.sites_per_wave;
     const int bpc = (waves + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
     const int nchunks = nbp / 64;
-    LaunchScope ls(h, T_STENCIL);
+    LaunchScope ls(h, mode == 0 ? T_STENCIL : (mode == 1 ? T_STENCIL_RES : T_STENCIL_SM));
     if (mode == 0)
       hipLaunchKernelGGL((swk::k_stencil<0>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
                          X, B, Y, a, bpc);
@@ -827,6 +838,8 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
 static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, double tol, int maxiter,
                   int m, bool outer, KrylovWS& ws, int nbp, int* iters_total) {
   Level& lv = H.lv[level];
+  const int hid_idx = (int)(&H - &h->hier[0]);
+  const int check_from = (outer && h->lazy_sync) ? std::max(0, h->sync_hint[hid_idx][level] - 2) : 0;
   const int n = lv.n;
   const size_t vec = (size_t)n * nbp;
   const bool precond = (level < H.nlevels - 1);
@@ -873,7 +886,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
         KLAUNCH_CHECK();
       }
       SWCHK(scale_to(h, ws.sc.scale, w, w, n, nbp));
-      if (outer) {
+      if (outer && (done + j + 1 >= check_from || done + j + 1 >= maxiter)) {
         HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost,
                               h->stream));
         SWCHK(stream_sync(h));
@@ -902,6 +915,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     }
   }
   if (iters_total) *iters_total = done;
+  if (outer) h->sync_hint[hid_idx][level] = done;
   return 0;
 }
 
@@ -1234,6 +1248,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (!h || !name) return 1;
   if (std::strcmp(name, "use_mfma") == 0) {
     h->use_mfma = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "lazy_sync") == 0) {
+    h->lazy_sync = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "mfma_tiles") == 0) {
@@ -1705,7 +1723,8 @@ int sw_timers(sw_engine* h, double t[8]) {
   if (!h || !t) return 1;
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
-  t[T_MVM] += h->tacc[T_STENCIL];
+  t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP];
+  t[T_COARSEST] += h->tacc[T_MFMA_DENSE];
   return 0;
 }
 int sw_timers_reset(sw_engine* h) {

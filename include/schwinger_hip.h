@@ -139,8 +139,12 @@ int sw_set_profiling(sw_engine* h, int on);
 int sw_timers(sw_engine* h, double t[8]);
 int sw_timers_reset(sw_engine* h);
 /* Accumulated HIP-event time and launch count of one kernel class since the last reset
- * (profiling on): classes 0..7 as sw_timers, 8 = the level-0 Wilson stencil kernel alone. */
-#define SW_KCLASS_STENCIL 8
+ * (profiling on): classes 0..7 as sw_timers (without the kernels listed next), and */
+#define SW_KCLASS_STENCIL 8         /* k_stencil<0>  Y = A X                       */
+#define SW_KCLASS_STENCIL_RES 9     /* k_stencil<1>  Y = B - A X                   */
+#define SW_KCLASS_STENCIL_SM 10     /* k_stencil<2>  Y = X + w (B - A X)           */
+#define SW_KCLASS_MFMA_DENSE 11     /* k_bsr_mfma, dense coarsest inverse          */
+#define SW_KCLASS_MFMA_OP 12        /* k_bsr_mfma, block-structured level operator */
 int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);
 /* Kernel launches issued since the last reset (for launch-bound analysis). */
 int sw_launch_count(sw_engine* h, int64_t* n);

@@ -53,10 +53,11 @@ def main(out):
             fmb = 2.0 * f[1] / f[0] * 1024 / 1e6 if f else float("nan")
             wmb = w[1] / w[0] * 1024 / 1e6 if w else float("nan")
             lines.append("%-72s %12.2f %12.2f %12.2f" % (k, fmb, wmb, fmb + wmb))
-            if "k_stencil<0>" in k:
-                summary["hbm_bytes_per_launch"] = (fmb + wmb) * 1e6
-                summary["fetch_bytes_per_launch_corrected"] = fmb * 1e6
-                summary["write_bytes_per_launch"] = wmb * 1e6
+            for tag in ("k_stencil<0>", "k_stencil<1>", "k_stencil<2>"):
+                if tag in k:
+                    summary[tag] = {"hbm_bytes_per_launch": (fmb + wmb) * 1e6,
+                                    "fetch_bytes_per_launch_corrected": fmb * 1e6,
+                                    "write_bytes_per_launch": wmb * 1e6}
     text = "\n".join(lines)
     open(os.path.join(out, "summary.txt"), "w").write(text + "\n")
     if summary:

@@ -54,10 +54,13 @@ def main():
     import torch.distributed as td
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; SW_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
+    backend = os.environ.get("SW_DIST_BACKEND", "nccl")
+    device_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+        td.init_process_group(backend=backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
@@ -71,7 +74,7 @@ def main():
     import io
     params = gateway.set_params('schwinger128')
     params['function_tol'] = args.tol
-    params['device'] = local_rank
+    params['device'] = device_index
     if args.cfg:
         params['solver_cfg'] = json.loads(args.cfg)
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
@@ -125,7 +128,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -117,9 +117,16 @@ struct sw_engine {
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
   bool lazy_sync = true;
+  // one Gram-Schmidt pass per Arnoldi step instead of two; every outer solve is then verified
+  // against its TRUE residual and continued when the recurrence was optimistic
+  bool cgs2 = false;
+  bool verify = true;
   // deflation
   int kd = 0;
   cplx* U = nullptr;  // [n0][kd] internal row order
+  // MLMC-level deflation vectors V_l (utils.py:260-266), [n_l][k_l] internal row order
+  int lkd[SW_MAX_LEVELS] = {0};
+  cplx* lV[SW_MAX_LEVELS] = {nullptr};
   // Pperm^T gathers and MLMC rhs maps (hid 0)
   int* perm_src[SW_MAX_LEVELS] = {nullptr};
   EllOp rhsmap[SW_MAX_LEVELS];
@@ -141,7 +148,7 @@ struct sw_engine {
   };
   std::vector<ProbeSlot> slots;
   cplx *pb_x0 = nullptr, *pb_rhs = nullptr, *pb_z = nullptr, *pb_xc = nullptr, *pb_xc2 = nullptr,
-       *pb_y = nullptr, *pb_w = nullptr, *pb_w2 = nullptr;
+       *pb_y = nullptr, *pb_w = nullptr, *pb_w2 = nullptr, *pb_xd = nullptr;
   int pb_ws_nbp = 0;
   cplx* pb_est = nullptr;
   int* pb_iters = nullptr;
@@ -874,10 +881,15 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       for (int k = 0; k <= j; ++k) pv.p[k] = ws.V + vec * k;
       // pass 1: h1 = V^H w ; w -= V h1
       SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h1));
-      SWCHK(multiaxpy(h, pv, j + 1, ws.h1, -1.0, w, w, n, nbp, nullptr));
-      // pass 2 (re-orthogonalisation): h2 = V^H w ; w -= V h2 ; ||w||^2
-      SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2));
-      SWCHK(multiaxpy(h, pv, j + 1, ws.h2, -1.0, w, w, n, nbp, ws.nrm));
+      if (h->cgs2 || !outer) {
+        SWCHK(multiaxpy(h, pv, j + 1, ws.h1, -1.0, w, w, n, nbp, nullptr));
+        // pass 2 (re-orthogonalisation): h2 = V^H w ; w -= V h2 ; ||w||^2
+        SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.h2, -1.0, w, w, n, nbp, ws.nrm));
+      } else {
+        SWCHK(multiaxpy(h, pv, j + 1, ws.h1, -1.0, w, w, n, nbp, ws.nrm));
+        HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
+      }
       if (outer) HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
       {
         LaunchScope ls(h, T_OTHER);
@@ -909,7 +921,27 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     done += k;
     first = false;
     if (!outer) break;
-    if (!converged && done < maxiter) {
+    if (converged && h->verify && done < maxiter) {
+      // true residual of every probe; continue when the Arnoldi recurrence was optimistic
+      SWCHK(apply_op(h, lv, 1, X, B, ws.rres, nbp));
+      PtrList pr;
+      pr.p[0] = ws.rres;
+      SWCHK(multidot(h, pr, 1, ws.rres, n, nbp, ws.nrm));
+      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
+      {
+        LaunchScope ls(h, T_OTHER);
+        hipLaunchKernelGGL(swk::k_fg_verify, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, tol);
+        KLAUNCH_CHECK();
+      }
+      HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost,
+                            h->stream));
+      SWCHK(stream_sync(h));
+      if (*h->h_notconv != 0) {
+        converged = false;
+        Rcur = ws.rres;
+        continue;
+      }
+    } else if (!converged && done < maxiter) {
       SWCHK(apply_op(h, lv, 1, X, B, ws.rres, nbp));
       Rcur = ws.rres;
     }
@@ -1250,6 +1282,14 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->use_mfma = value != 0.0;
     return 0;
   }
+  if (std::strcmp(name, "cgs2") == 0) {
+    h->cgs2 = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "verify") == 0) {
+    h->verify = value != 0.0;
+    return 0;
+  }
   if (std::strcmp(name, "lazy_sync") == 0) {
     h->lazy_sync = value != 0.0;
     return 0;
@@ -1279,6 +1319,26 @@ int sw_set_deflation(sw_engine* h, int k, const double* U) {
   }
   SWCHK(upload(h, (std::complex<double>**)&h->U, Ui.data(), Ui.size()));
   h->kd = k;
+  return 0;
+}
+
+int sw_set_level_deflation(sw_engine* h, int level, int k, const double* V) {
+  SWCHK(check_hier(h, 0, level, false));
+  if (k < 0 || k > SW_MAX_DEFL) return sw_fail(h, "deflation rank %d out of [0,%d]", k, SW_MAX_DEFL);
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[0].lv[level];
+  h->lkd[level] = 0;
+  if (k == 0) return 0;
+  if (!V) return sw_fail(h, "null deflation vectors");
+  if (lv.n <= 0) return sw_fail(h, "level %d undefined", level);
+  const std::complex<double>* Vh = (const std::complex<double>*)V;
+  std::vector<std::complex<double>> Vi((size_t)lv.n * k);
+  for (int i = 0; i < lv.n; ++i) {
+    const int r = lv.h_rowmap.empty() ? i : lv.h_rowmap[i];
+    for (int q = 0; q < k; ++q) Vi[(size_t)r * k + q] = Vh[(size_t)i * k + q];
+  }
+  SWCHK(upload(h, (std::complex<double>**)&h->lV[level], Vi.data(), Vi.size()));
+  h->lkd[level] = k;
   return 0;
 }
 
@@ -1455,6 +1515,7 @@ static int ensure_probe_ws(sw_engine* h, int nbp) {
   SWCHK(dev_realloc(h, &h->pb_y, cnt));
   SWCHK(dev_realloc(h, &h->pb_w, cnt));
   SWCHK(dev_realloc(h, &h->pb_w2, cnt));
+  SWCHK(dev_realloc(h, &h->pb_xd, cnt));
   SWCHK(dev_realloc(h, &h->pb_est, (size_t)4 * nbp));
   SWCHK(dev_realloc(h, &h->pb_iters, (size_t)2 * nbp));
   h->pb_ws_nbp = nbp;
@@ -1518,6 +1579,46 @@ static int record_iters(sw_engine* h, KrylovWS* ws, int total_or_const, std::vec
   return 0;
 }
 
+// out[r] = X[s] - sum_k U[s][k] (U^H X)[k],  s = srcrow[r] (NULL: identity)   (utils.py:221-225)
+static int deflate(sw_engine* h, const cplx* U, int kd, const int* srcrow, const cplx* X, cplx* out,
+                   int n, int nbp) {
+  int P, rpb;
+  row_blocking(n, nbp, true, &P, &rpb);
+  cplx* cbuf = h->small + 8 * nbp;  // [kd][nbp], kd <= SW_MAX_DEFL
+  for (int k0 = 0; k0 < kd; k0 += 32) {
+    const int kc = std::min(32, kd - k0);
+    SWCHK(ensure_partial(h, (size_t)P * kc * nbp * sizeof(cplx)));
+    {
+      LaunchScope ls(h, T_DEFL);
+      dim3 grid(P, nbp / 64);
+      if (kc <= 8)
+        hipLaunchKernelGGL((swk::k_defl_dots<8>), grid, dim3(SW_BLOCK), 0, h->stream,
+                           (const cplx*)(U + k0), kd, kc, X, n, nbp, rpb, h->partial);
+      else if (kc <= 16)
+        hipLaunchKernelGGL((swk::k_defl_dots<16>), grid, dim3(SW_BLOCK), 0, h->stream,
+                           (const cplx*)(U + k0), kd, kc, X, n, nbp, rpb, h->partial);
+      else
+        hipLaunchKernelGGL((swk::k_defl_dots<32>), grid, dim3(SW_BLOCK), 0, h->stream,
+                           (const cplx*)(U + k0), kd, kc, X, n, nbp, rpb, h->partial);
+      KLAUNCH_CHECK();
+    }
+    {
+      LaunchScope ls(h, T_DEFL);
+      hipLaunchKernelGGL(swk::k_reduce_partials, dim3(kc, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
+                         h->partial, P, kc, nbp, cbuf + (size_t)k0 * nbp);
+      KLAUNCH_CHECK();
+    }
+  }
+  {
+    LaunchScope ls(h, T_DEFL);
+    dim3 grid((n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
+    hipLaunchKernelGGL(swk::k_defl_apply, grid, dim3(SW_BLOCK), 0, h->stream, U, kd, cbuf, srcrow, X,
+                       out, n, nbp);
+    KLAUNCH_CHECK();
+  }
+  return 0;
+}
+
 int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
   SWCHK(check_hier(h, 0, level, true));
   if (h->pb_level != level || h->pb_nb <= 0) return sw_fail(h, "no probes uploaded for level %d", level);
@@ -1544,40 +1645,7 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
     // rhs = Pperm^T (x - U U^H x)          utils.py:221-233
     const int kd = h->kd;
     if (kd > 0) {
-      int P, rpb;
-      row_blocking(n, nbp, true, &P, &rpb);
-      cplx* cbuf = h->small + 8 * nbp;  // [kd][nbp], kd <= SW_MAX_DEFL
-      for (int k0 = 0; k0 < kd; k0 += 32) {
-        const int kc = std::min(32, kd - k0);
-        SWCHK(ensure_partial(h, (size_t)P * kc * nbp * sizeof(cplx)));
-        {
-          LaunchScope ls(h, T_DEFL);
-          dim3 grid(P, nbp / 64);
-          if (kc <= 8)
-            hipLaunchKernelGGL((swk::k_defl_dots<8>), grid, dim3(SW_BLOCK), 0, h->stream,
-                               (const cplx*)(h->U + k0), kd, kc, h->pb_x0, n, nbp, rpb, h->partial);
-          else if (kc <= 16)
-            hipLaunchKernelGGL((swk::k_defl_dots<16>), grid, dim3(SW_BLOCK), 0, h->stream,
-                               (const cplx*)(h->U + k0), kd, kc, h->pb_x0, n, nbp, rpb, h->partial);
-          else
-            hipLaunchKernelGGL((swk::k_defl_dots<32>), grid, dim3(SW_BLOCK), 0, h->stream,
-                               (const cplx*)(h->U + k0), kd, kc, h->pb_x0, n, nbp, rpb, h->partial);
-          KLAUNCH_CHECK();
-        }
-        {
-          LaunchScope ls(h, T_DEFL);
-          hipLaunchKernelGGL(swk::k_reduce_partials, dim3(kc, nbp / 64), dim3(SW_BLOCK), 0,
-                             h->stream, h->partial, P, kc, nbp, cbuf + (size_t)k0 * nbp);
-          KLAUNCH_CHECK();
-        }
-      }
-      {
-        LaunchScope ls(h, T_DEFL);
-        dim3 grid((n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
-        hipLaunchKernelGGL(swk::k_defl_apply, grid, dim3(SW_BLOCK), 0, h->stream, h->U, kd, cbuf,
-                           (const int*)h->perm_src[0], h->pb_x0, h->pb_rhs, n, nbp);
-        KLAUNCH_CHECK();
-      }
+      SWCHK(deflate(h, h->U, kd, (const int*)h->perm_src[0], h->pb_x0, h->pb_rhs, n, nbp));
     } else {
       LaunchScope ls(h, T_DEFL);
       dim3 grid((n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
@@ -1600,8 +1668,13 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
   if (lcoarse >= H0.nlevels) return sw_fail(h, "no coarse level %d", lcoarse);
   // x_def = Bblock_perm * Pperm^T * x0      utils.py:288-290
   const cplx* xdef = h->pb_x0;
+  if (h->lkd[level] > 0) {
+    // x_def = x0 - V V^H x0                 utils.py:260-266 (defl_type exact / inexact_01)
+    SWCHK(deflate(h, h->lV[level], h->lkd[level], nullptr, h->pb_x0, h->pb_xd, n, nbp));
+    xdef = h->pb_xd;
+  }
   if (h->rhsmap[level].set) {
-    SWCHK(launch_ell(h, h->rhsmap[level], 0, h->pb_x0, nullptr, h->pb_rhs, nbp, T_OTHER));
+    SWCHK(launch_ell(h, h->rhsmap[level], 0, xdef, nullptr, h->pb_rhs, nbp, T_OTHER));
     xdef = h->pb_rhs;
   }
   int total_f = 0, total_c = 0;

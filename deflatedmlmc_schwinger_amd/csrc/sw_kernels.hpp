@@ -725,6 +725,20 @@ __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
   }
 }
 
+// true-residual check after a solve: d[col].x = ||b - A x||^2; probes above tol are counted and
+// lose their recorded iteration (it is set again when they converge in a later cycle)
+__global__ void k_fg_verify(FgScalars s, const cplx* __restrict__ d, double tol) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= s.nbp) return;
+  const double nb_ = s.normb[col].x;
+  const double rr = (nb_ > 0.0) ? sqrt(fmax(d[col].x, 0.0)) / nb_ : 0.0;
+  s.relres[col] = cmake(rr, 0.0);
+  if (rr >= tol) {
+    s.iters[col] = -1;
+    atomicAdd(s.notconv, 1);
+  }
+}
+
 // y = H(0:k,0:k)^-1 g(0:k) per probe
 __global__ void k_fg_solve(FgScalars s, int k) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;

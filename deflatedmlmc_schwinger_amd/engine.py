@@ -64,6 +64,7 @@ def load_library():
     sig("sw_set_smoother", i32, vp, i32, i32, i32, vp, i32, vp)
     sig("sw_hier_end", i32, vp, i32)
     sig("sw_set_deflation", i32, vp, i32, vp)
+    sig("sw_set_level_deflation", i32, vp, i32, i32, vp)
     sig("sw_set_perm", i32, vp, i32, i64)
     sig("sw_set_rhsmap", i32, vp, i32, i32, vp, vp, vp)
     sig("sw_set_solver", i32, vp, i32, i32)
@@ -99,7 +100,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_set_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
+    "sw_set_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -217,6 +218,15 @@ class Engine:
             return
         U = _c128(np.asarray(U))
         self._chk(self._lib.sw_set_deflation(self._h, U.shape[1], _ptr(U)), "sw_set_deflation")
+
+    def set_level_deflation(self, level, V):
+        if V is None:
+            self._chk(self._lib.sw_set_level_deflation(self._h, level, 0, None),
+                      "sw_set_level_deflation")
+            return
+        V = _c128(np.asarray(V))
+        self._chk(self._lib.sw_set_level_deflation(self._h, level, V.shape[1], _ptr(V)),
+                  "sw_set_level_deflation")
 
     def set_perm(self, level, shift):
         self._chk(self._lib.sw_set_perm(self._h, level, int(shift)), "sw_set_perm")

@@ -12,6 +12,7 @@ from math import sqrt
 
 import numpy as np
 from scipy.sparse import csr_matrix
+from scipy.sparse.linalg import LinearOperator
 
 from . import dist as _dist
 from .multigrid import MG
@@ -196,15 +197,20 @@ def mlmc(A, params):
     print("Computing deflation vectors ...", end='', flush=True)
     t0 = time.time()
     nr_deflat_vctrs = params['mlmc_deflat_vctrs']
+    tolx = params['defl_eigvs_tol_MLMC']
     tr1s = []
     for ix in range(nr_levels - 1):
         if skip_level and ix == 1:
             tr1s.append(0.0)
             continue
-        if nr_deflat_vctrs[ix] > 0:
-            raise Exception("MLMC-level deflation (mlmc_deflat_vctrs > 0) is not wired into the "
-                            "GPU probe path yet; the shipped presets use 0")
-        tr1s.append(0.0)
+        # eigenvectors of the difference operator (A_f^-1 - P A_c^-1 R) g3   stoch_trace.py:257-270
+        mg_solver.level_for_diff_op = ix
+        n_ix = mg_solver.ml.levels[ix].A.shape[0]
+        lop = LinearOperator((n_ix, n_ix), dtype=np.complex128,
+                             matvec=lambda v: mg_solver.diff_op_Q(np.array(v, dtype=np.complex128)))
+        _, _, tr1 = deflation_pre_computations(A, nr_deflat_vctrs[ix], tolx, "mlmc", mg_solver.timer,
+                                               params, mg_solver, lop, level_nr=ix)
+        tr1s.append(tr1)
     print(" done. Time : " + str(time.time() - t0) + " seconds")
     print(mg_solver.timer)
 

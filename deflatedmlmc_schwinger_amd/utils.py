@@ -137,6 +137,8 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
             if mg_solver.engine is not None:
                 mg_solver.engine.set_deflation(None)
             return (None, 0.0)
+        if mg_solver.engine is not None:
+            mg_solver.engine.set_level_deflation(level_nr, None)
         return (None, None, 0.0)
 
     lev0 = mg_solver.ml.levels[0]
@@ -159,6 +161,9 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
             Ux = lev0.Pperm * Ux
     else:
         Vx = mg_solver.ml.levels[level_nr].g3 * Vx
+        if mg_solver.engine is not None:
+            # the GPU probe body projects with these vectors (utils.py:260-266)
+            mg_solver.engine.set_level_deflation(level_nr, np.asarray(Vx))
 
     if os.getenv('OMP_NUM_THREADS') is None:                            # utils.py:161-164
         raise Exception("Run : << export OMP_NUM_THREADS=N >>")
@@ -233,9 +238,14 @@ def one_defl_Hutch_step(Af, Ac, mg_solver, params, method, nr_deflat_vctrs, Vx, 
         itrs = int(itf[0])
         est = e[0]
     elif method == "mlmc":
-        if nr_deflat_vctrs > 0:
-            raise Exception("MLMC-level deflation (mlmc_deflat_vctrs > 0) is not wired into the "
-                            "GPU probe path yet; the shipped presets use 0")
+        if nr_deflat_vctrs > 0 and params['defl_type'] not in ("exact", "inexact_01"):
+            if params['defl_type'] == "inexact_02":
+                raise Exception("deflation type inexact_02 under construction")
+            if params['defl_type'] == "inexact_03":
+                raise Exception("deflation type inexact_03 is not available on the GPU probe path")
+            raise Exception("unknown deflation type")
+        # with nr_deflat_vctrs > 0 the projection x0 - V V^H x0 (utils.py:266) uses the vectors that
+        # deflation_pre_computations registered with the engine for level i
         probes = draw_probes(1, n)
         mg_solver.level_nr = i
         e, itf, itc = probe_batch(mg_solver, params, "mlmc", probes, i)

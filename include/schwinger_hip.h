@@ -75,6 +75,9 @@ int sw_hier_end(sw_engine* h, int hid);
 
 /* Deflation vectors U (utils.py:145-155), row-major complex128[n0*k], reference ordering. */
 int sw_set_deflation(sw_engine* h, int k, const double* U);
+/* MLMC-level deflation vectors V_l of the difference operator at `level` of hid 0
+ * (utils.py:141-157,260-266), row-major complex128[n_l*k]; k = 0 clears. */
+int sw_set_level_deflation(sw_engine* h, int level, int k, const double* V);
 /* Index shift of Pperm at `level` of hid 0 (multigrid.py:142-155,320-326). shift<0 clears. */
 int sw_set_perm(sw_engine* h, int level, int64_t shift);
 /* MLMC right-hand-side map C_i = Bblock_perm_i * Pperm_i^T as CSR (multigrid.py:328-331,

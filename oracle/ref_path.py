@@ -417,11 +417,11 @@ def hutch_probe(x, solve, Ux, PpermT):
     return np.vdot(x, z)
 
 
-def mlmc_probe(x0, i, levels, skip_level, solve_level, coarsest_inv, use_permuted):
-    """utils.py:284-355 (no MLMC-level deflation: mlmc_deflat_vctrs = 0).
+def mlmc_probe(x0, i, levels, skip_level, solve_level, coarsest_inv, use_permuted, Vx=None):
+    """utils.py:260-355; Vx = MLMC-level deflation vectors (utils.py:266) or None.
     solve_level(l, b) -> A_l^-1 b."""
     nlev = len(levels)
-    x_def = x0
+    x_def = x0 if Vx is None else x0 - Vx @ (Vx.conj().T @ x0)
     if use_permuted:
         x_perm = levels[i].Pperm.transpose() @ x_def
         x_def = levels[i].Bblock_perm @ x_perm

@@ -307,3 +307,89 @@ def test_full_deflated_hutchinson_flow_128_within_reported_error(capsys):
     err = res['std_dev'] / np.sqrt(n)
     assert abs(res['trace'] - EXACT_128) < 4.0 * err
     assert res['function_iters'] >= n
+
+
+@pytest.mark.parametrize("L", [8, 32, 64])
+def test_synthetic_lattices_stencil_and_solve(L):
+    """random U(1) gauge fields at other lattice sizes (towards BASELINE config 5): stencil vs
+    CSR, batched solve vs LU, plain Hutchinson probes vs LU -- without any multigrid levels
+    (single-level hierarchy, unpreconditioned GMRES) and, for L = 64, with the solver hierarchy."""
+    from deflatedmlmc_schwinger_amd.engine import Engine
+    from deflatedmlmc_schwinger_amd import hierarchy
+    mass = 0.05
+    A = matrix.synthetic_matrix(L, mass, sigma=0.3, seed=100 + L)
+    n = A.shape[0]
+    lat = hierarchy.detect_lattice(A)
+    assert lat is not None and lat[0] == L
+    eng = Engine(0)
+    eng.hier_begin(0, 1)
+    eng.set_lattice(0, L, lat[1], lat[2], lat[3])
+    eng.hier_end(0)
+    eng.set_solver(32, 0)
+    X = _rand((5, n), L)
+    assert _relerr(eng.apply_dirac(0, 0, X), (A @ X.T).T) < 1e-13
+    lu = rp.LUSolver(A)
+    B = _rand((3, n), L + 1)
+    Xs, its, rr = eng.solve(0, 0, B, 1e-11, 2000)
+    assert rr.max() < 1e-11
+    ref = np.stack([lu(b) for b in B])
+    assert _relerr(Xs, ref) < 1e-8
+    np.random.seed(L)
+    probes = utils.draw_probes(4, n)
+    ests, _, _ = eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 4000)
+    for k in range(4):
+        refe = rp.hutch_probe(probes[k].astype(np.complex128), lu, None, None)
+        assert abs(ests[k] - refe) / abs(refe) < 1e-9
+    eng.close()
+    if L == 64:
+        mg = MG(A)
+        tp = {'use_permuted': False, 'test_vectors_type': 'EVs', 'latt_dims': [L, L],
+              'x_displacement': 0, 'solver_cfg': dict(hierarchy.DEFAULT_SOLVER_CFG)}
+        mg.setup(dof=[2, 8, 8], aggrs=[16, 4], max_levels=3, dim=2, acc_eigvs='high',
+                 sys_type='schwinger', params=tp)
+        Xs, its, rr = mg.solve_batch(0, B, 1e-12)
+        assert rr.max() < 1e-12 and its.max() < 60
+        assert _relerr(Xs, ref) < 1e-9
+
+
+def test_mlmc_level_deflation_projection_matches_oracle(p16):
+    """probe body with MLMC-level deflation vectors registered (utils.py:260-266)."""
+    p = p16
+    cinv = np.asarray(p.mg.coarsest_inv)
+    rng = np.random.default_rng(11)
+    for level in (0, 1):
+        n = p.levels[level].A.shape[0]
+        V, _ = np.linalg.qr(rng.standard_normal((n, 5)) + 1j * rng.standard_normal((n, 5)))
+        p.eng.set_level_deflation(level, V)
+        try:
+            np.random.seed(300 + level)
+            probes = utils.draw_probes(4, n)
+            ests, _, _ = p.eng.hutch_batch(MODE_MLMC, level, probes, 1e-12, 1000)
+        finally:
+            p.eng.set_level_deflation(level, None)
+        for k in range(4):
+            ref = rp.mlmc_probe(probes[k].astype(np.complex128), level, p.levels, False,
+                                lambda l, b: p.lu_solver(l)(b), cinv, False, Vx=V)
+            assert abs(ests[k] - ref) < 1e-9 * max(1.0, abs(ref))
+
+
+def test_full_deflated_mlmc_flow_16(capsys):
+    """G201-like: MLMC with deflation of the difference operators (mlmc_deflat_vctrs > 0) on
+    16^2; eigenvectors computed tightly so the estimator is unbiased to the test's resolution."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    params = gateway.set_params('schwinger16')
+    params['function_tol'] = 1e-12
+    params['nr_deflat_vctrs'] = 8
+    params['mlmc_deflat_vctrs'] = [8, 8]
+    params['defl_eigvs_tol_MLMC'] = 1.0e-8
+    params['diff_lev_op_tol'] = 1.0e-11
+    params['trace_tol'] = 2.0e-2
+    params['accuracy_mg_eigvs'] = 'high'
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    tp['batch'] = 64
+    res = stoch_trace.mlmc(A, tp)
+    capsys.readouterr()
+    exact = 265.8581064657958
+    err2 = sum(res['results'][i]['ests_dev'] ** 2 / (res['results'][i]['nr_ests'] + 1) for i in (0,))
+    assert abs(res['trace'] - exact) < 4.0 * np.sqrt(err2) + 1e-6 * exact, (res['trace'], np.sqrt(err2))

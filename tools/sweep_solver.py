@@ -45,6 +45,9 @@ def main():
         last_key, tv = key, mg.solver_testvectors
         eng.set_option("use_mfma", float(cfg.get("use_mfma", 1)))
         eng.set_option("mfma_tiles", float(cfg.get("mfma_tiles", 4)))
+        for key, val in cfg.items():
+            if key.startswith("opt_"):
+                eng.set_option(key[4:], float(val))
         t_setup = time.time() - t0
         eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
         eng.sync()

@@ -35,11 +35,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nb", type=int, default=256, help="probes per GPU per step")
+    ap.add_argument("--nb", type=int, default=256, help="probes per engine stream per step")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "2")),
+                    help="concurrent probe batches (engine handles / HIP streams) per GPU")
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
                     help="JSON solver-hierarchy override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-stencil", action="store_true",
+                    help="skip the synthetic 1024^2 stencil roofline point")
     ap.add_argument("--cpu-probes", type=int, default=2)
     ap.add_argument("--quiet-setup", action="store_true", default=True)
     return ap.parse_args()
@@ -75,6 +79,7 @@ def main():
     params = gateway.set_params('schwinger128')
     params['function_tol'] = args.tol
     params['device'] = device_index
+    params['engines'] = max(1, args.streams)
     if args.cfg:
         params['solver_cfg'] = json.loads(args.cfg)
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
@@ -97,19 +102,32 @@ def main():
     maxiter = 1000
 
     # ---- inputs: probes of every step, resident in HBM before timing ---------------------
+    engs = mg.engines
+    ne = len(engs)
     nsteps = args.warmup + args.steps + 1          # +1: instrumented step
     stream = ProbeStream(123456)
     for s in range(nsteps):
-        stream.skip(rank * nb * n)
-        probes = stream.rademacher(nb, n)
-        stream.skip((world - 1 - rank) * nb * n)
-        eng.probes_upload_slot(s, 0, probes)
+        # a round = world * ne batches of nb probes, contiguous blocks per (rank, stream)
+        stream.skip(rank * ne * nb * n)
+        for e in range(ne):
+            engs[e].probes_upload_slot(s, 0, stream.rademacher(nb, n))
+        stream.skip((world - 1 - rank) * ne * nb * n)
     comm = swdist.TorchComm() if world > 1 else swdist.Comm()
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=ne)
+
+    def run_one(e, s):
+        engs[e].probes_select(s)
+        engs[e].hutch_run(MODE_HUTCHINSON, 0, args.tol, maxiter)
+        return engs[e].hutch_fetch()
 
     def step(s):
-        eng.probes_select(s)
-        eng.hutch_run(MODE_HUTCHINSON, 0, args.tol, maxiter)
-        ests, itf, _ = eng.hutch_fetch()
+        if ne == 1:
+            res = [run_one(0, s)]
+        else:
+            res = list(pool.map(lambda e: run_one(e, s), range(ne)))
+        ests = np.concatenate([r[0] for r in res])
+        itf = np.concatenate([r[1] for r in res])
         stats = comm.allreduce_stats(swdist.local_stats(ests))
         return ests, itf, stats
 
@@ -136,7 +154,7 @@ def main():
     # ---- instrumented step: HIP events around every launch, on the engine stream ----------
     eng.set_profiling(True)
     eng.timers_reset()
-    step(args.warmup + args.steps)
+    run_one(0, args.warmup + args.steps)      # one stream alone: clean per-kernel durations
     kstats = {name: eng.kernel_stats(cls) for name, cls in
               (("k_stencil<0>", 8), ("k_stencil<1>", 9), ("k_stencil<2>", 10),
                ("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12))}
@@ -187,7 +205,7 @@ def main():
         bytes0 = algo["k_stencil<0>"][1]
         out = {
             "metric": "hutchinson_probe_samples_per_sec_schwinger128",
-            "value": world * args.steps * nb / elapsed,
+            "value": world * ne * args.steps * nb / elapsed,
             "unit": "probe-samples/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -200,9 +218,11 @@ def main():
             "data": "synthetic Rademacher probes (MT19937 seed 123456) on the schwinger128 gauge "
                     "configuration (link fixture), m0=-0.1320",
             "config": {
-                "workload": "schwinger128, %d probes/GPU/step as one multi-RHS batch, deflated "
-                            "Hutchinson (k=8, Pperm shift 512), fp64, tol %.0e" % (nb, args.tol),
-                "probes_per_step_per_gpu": nb,
+                "workload": "schwinger128, %d x %d probes/GPU/step (%d concurrent multi-RHS batches "
+                            "of %d on separate HIP streams), deflated Hutchinson (k=8, Pperm shift "
+                            "512), fp64, tol %.0e" % (ne, nb, ne, nb, args.tol),
+                "probes_per_step_per_gpu": ne * nb,
+                "streams_per_gpu": ne,
                 "solver": mg.solver_info,
                 "outer_iterations_max": max(iters_seen) if iters_seen else None,
                 "trace_estimate": [float(np.real(mean + tr1)), float(np.imag(mean + tr1))],
@@ -218,12 +238,35 @@ def main():
             "kernel_rooflines": rooflines,
             "step_breakdown_ms": dict(buckets, kernel_launches=launches),
         }
+        if not args.no_large_stencil:
+            out["stencil_roofline_1024"] = large_stencil_point()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes)
         print(json.dumps(out))
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def large_stencil_point(L=1024, nb=64, reps=20):
+    """HBM roofline point of the stencil beyond the 256 MB Infinity Cache (BASELINE config 5's
+    lattice): synthetic random U(1) links on L^2 sites, nb probes, back-to-back launches."""
+    from deflatedmlmc_schwinger_amd import matrix as swm
+    from deflatedmlmc_schwinger_amd.engine import Engine
+    U1, U2 = swm.synthetic_links(L, 0.45, 2024)
+    import torch
+    eng = Engine(torch.cuda.current_device())
+    eng.hier_begin(0, 1)
+    eng.set_lattice(0, L, -0.05, U1, U2)
+    eng.hier_end(0)
+    ms = eng.bench_dirac(0, 0, nb, reps)
+    nbp = ((nb + 63) // 64) * 64
+    work = L * L * (64.0 * nbp + 32.0)
+    eng.close()
+    ach = work / (ms * 1e-3) / 1e9
+    return {"kernel": "k_stencil<0>", "workload": "synthetic %dx%d, %d probes, back-to-back" % (L, L, nb),
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "work_per_launch": work, "avg_launch_ms": ms}
 
 
 def cpu_baseline(A, tp, mg, nprobes):

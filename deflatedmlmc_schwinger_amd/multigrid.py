@@ -41,7 +41,8 @@ class MG:
         self.timer = CustomTimer()
         self.skip_level = False
         # build-specific state
-        self.engine = None
+        self.engine = None        # first engine handle (building blocks, single-RHS calls)
+        self.engines = []         # all handles: concurrent probe batches use one stream each
         self.device = 0
         self.solver_info = None
         self.testvectors = None
@@ -75,34 +76,40 @@ class MG:
 
     def _upload(self, params):
         device = int(params.get("device", self.device)) if params else self.device
+        nr_engines = max(1, int(params.get("engines", 1))) if params else 1
         if self.engine is None:
-            self.engine = Engine(device)
-        eng = self.engine
+            self.engines = [Engine(device) for _ in range(nr_engines)]
+            self.engine = self.engines[0]
         levels = self.ml.levels
         nlev = len(levels)
         lat = _hier.detect_lattice(levels[0].A)
         self.lattice = lat
-        eng.hier_begin(REF_HID, nlev)
-        if lat is not None:
-            L, mass, U1, U2 = lat
-            eng.set_lattice(REF_HID, L, mass, U1, U2)
-        else:
-            eng.set_csr(REF_HID, 0, levels[0].A)
-        for i in range(nlev - 1):
-            if i > 0:
-                eng.set_csr(REF_HID, i, levels[i].A)
-            eng.set_transfer(REF_HID, i, levels[i].P)
-            # MR(nu) stands in for lgmres(maxiter=smooth_iters); see DESIGN.md section 4
-            eng.set_cycle(REF_HID, i, 0, int(params.get("ref_cycle_post", 4)) if params else 4,
-                          int(params.get("ref_cycle_k", 0)) if params else 0)
-        eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A) if nlev > 1 else None
-        eng.set_coarsest_inv(REF_HID, np.asarray(self.coarsest_inv))
-        eng.hier_end(REF_HID)
+        cinv = np.asarray(self.coarsest_inv)
+        rhsmaps = {}
         for i in range(nlev):
             if params and params.get("use_permuted") and not isinstance(levels[i].Pperm, int):
+                rhsmaps[i] = sp.csr_matrix(levels[i].Bblock_perm @ levels[i].Pperm.transpose())
+        for eng in self.engines:
+            eng.hier_begin(REF_HID, nlev)
+            if lat is not None:
+                L, mass, U1, U2 = lat
+                eng.set_lattice(REF_HID, L, mass, U1, U2)
+            else:
+                eng.set_csr(REF_HID, 0, levels[0].A)
+            for i in range(nlev - 1):
+                if i > 0:
+                    eng.set_csr(REF_HID, i, levels[i].A)
+                eng.set_transfer(REF_HID, i, levels[i].P)
+                # MR(nu) stands in for lgmres(maxiter=smooth_iters); see DESIGN.md section 4
+                eng.set_cycle(REF_HID, i, 0, int(params.get("ref_cycle_post", 4)) if params else 4,
+                              int(params.get("ref_cycle_k", 0)) if params else 0)
+            if nlev > 1:
+                eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A)
+            eng.set_coarsest_inv(REF_HID, cinv)
+            eng.hier_end(REF_HID)
+            for i, Cmat in rhsmaps.items():
                 eng.set_perm(i, int(levels[i].perm_shift))
-                Cmat = levels[i].Bblock_perm @ levels[i].Pperm.transpose()
-                eng.set_rhsmap(i, sp.csr_matrix(Cmat))
+                eng.set_rhsmap(i, Cmat)
         # level-0 preconditioner
         cfg = params.get("solver_cfg") if params else None
         want = True if params is None else params.get("use_solver_hierarchy", True)
@@ -110,11 +117,12 @@ class MG:
         if want and lat is not None:
             self.upload_solver_hierarchy(cfg, params.get("solver_testvectors") if params else None)
         else:
-            eng.set_solver(24, REF_HID)
+            for eng in self.engines:
+                eng.set_solver(24, REF_HID)
 
     def upload_solver_hierarchy(self, cfg=None, testvectors=None):
         """(Re)build the level-0 preconditioner hierarchy from `cfg` and make it the solver."""
-        eng = self._need_engine()
+        self._need_engine()
         lat = self.lattice
         if lat is None:
             raise Exception("the solver hierarchy needs a lattice operator at level 0")
@@ -128,30 +136,34 @@ class MG:
         t0 = time.time()
         sh = _hier.solver_hierarchy(self.ml.levels[0].A, L, cfg, testvectors=testvectors)
         nl = len(sh["A"])
-        eng.hier_begin(SOLVER_HID, nl)
-        eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
         self.solver_hier = sh
         self.solver_weights = []
         for i in range(nl - 1):
-            if i > 0:
-                eng.set_csr(SOLVER_HID, i, sh["A"][i])
-            eng.set_transfer(SOLVER_HID, i, sh["P"][i])
             cyc = cfg["cycle"][i]
-            eng.set_cycle(SOLVER_HID, i, cyc[0], cyc[1], cyc[2])
             if cfg.get("smoother", "richardson") == "richardson":
-                wts = (_hier.smoother_weights(sh["A"][i], cyc[0]),
-                       _hier.smoother_weights(sh["A"][i], cyc[1]))
-                eng.set_smoother(SOLVER_HID, i, wts[0], wts[1])
-                self.solver_weights.append(wts)
+                self.solver_weights.append((_hier.smoother_weights(sh["A"][i], cyc[0]),
+                                            _hier.smoother_weights(sh["A"][i], cyc[1])))
             else:
                 self.solver_weights.append(None)
-        eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
-        eng.hier_end(SOLVER_HID)
+        for eng in self.engines:
+            eng.hier_begin(SOLVER_HID, nl)
+            eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
+            for i in range(nl - 1):
+                if i > 0:
+                    eng.set_csr(SOLVER_HID, i, sh["A"][i])
+                eng.set_transfer(SOLVER_HID, i, sh["P"][i])
+                cyc = cfg["cycle"][i]
+                eng.set_cycle(SOLVER_HID, i, cyc[0], cyc[1], cyc[2])
+                if self.solver_weights[i] is not None:
+                    eng.set_smoother(SOLVER_HID, i, self.solver_weights[i][0],
+                                     self.solver_weights[i][1])
+            eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
+            eng.hier_end(SOLVER_HID)
+            eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
         self._have_solver_hier = True
         self.solver_testvectors = sh["tv"]
         self.solver_info = {"levels": [a.shape[0] for a in sh["A"]],
                             "setup_s": time.time() - t0, "cfg": cfg}
-        eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
 
     # ------------------------------------------------------------------------------------
     def _need_engine(self):

@@ -57,7 +57,7 @@ _COMMON_KEYS = ('max_nr_levels', 'nr_deflat_vctrs', 'defl_eigvs_tol_Hutch', 'acc
 _MLMC_KEYS = ('mlmc_deflat_vctrs', 'defl_eigvs_tol_MLMC', 'diff_lev_op_tol', 'defl_type',
               'coarsest_level_directly', 'mlmc_levels_to_skip')
 # build-only options (all optional; reference presets do not carry them)
-_BUILD_KEYS = ('batch', 'device', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
+_BUILD_KEYS = ('batch', 'device', 'engines', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
                'solver_testvectors', 'deflation_eigenpairs', 'ref_cycle_post', 'ref_cycle_k',
                'verbose', 'probe_rounds_max')
 
@@ -125,6 +125,13 @@ class CustomTimer:
         return "\n".join(lines)
 
 
+def _engines(mg_solver):
+    engs = getattr(mg_solver, "engines", None)
+    if engs:
+        return engs
+    return [mg_solver.engine] if getattr(mg_solver, "engine", None) is not None else []
+
+
 # ----------------------------------------------------------------------------------------
 # deflation (setup-time, host)                                          utils.py:130-201
 # ----------------------------------------------------------------------------------------
@@ -134,11 +141,11 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
         raise Exception("unknown deflation method")
     if nr_deflat_vctrs <= 0:
         if method == "hutchinson":
-            if mg_solver.engine is not None:
-                mg_solver.engine.set_deflation(None)
+            for eng in _engines(mg_solver):
+                eng.set_deflation(None)
             return (None, 0.0)
-        if mg_solver.engine is not None:
-            mg_solver.engine.set_level_deflation(level_nr, None)
+        for eng in _engines(mg_solver):
+            eng.set_level_deflation(level_nr, None)
         return (None, None, 0.0)
 
     lev0 = mg_solver.ml.levels[0]
@@ -161,9 +168,9 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
             Ux = lev0.Pperm * Ux
     else:
         Vx = mg_solver.ml.levels[level_nr].g3 * Vx
-        if mg_solver.engine is not None:
+        for eng in _engines(mg_solver):
             # the GPU probe body projects with these vectors (utils.py:260-266)
-            mg_solver.engine.set_level_deflation(level_nr, np.asarray(Vx))
+            eng.set_level_deflation(level_nr, np.asarray(Vx))
 
     if os.getenv('OMP_NUM_THREADS') is None:                            # utils.py:161-164
         raise Exception("Run : << export OMP_NUM_THREADS=N >>")
@@ -172,8 +179,8 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
     overlap = np.dot(Ux.transpose().conjugate(), Vx)
     if method == "hutchinson":
         tr1 = np.sum(np.diag(overlap) / Sabs)                           # utils.py:173,191
-        if mg_solver.engine is not None:
-            mg_solver.engine.set_deflation(np.asarray(Ux))
+        for eng in _engines(mg_solver):
+            eng.set_deflation(np.asarray(Ux))
         return (Ux, tr1)
     defl_type = params['defl_type']
     if defl_type == "exact":
@@ -209,8 +216,8 @@ def probe_batch(mg_solver, params, method, probes, level=0):
     hutchinson: e = x^H A^-1 Pperm^T (x - U U^H x)            utils.py:210-250
     mlmc      : e = x^H A_f^-1 C x - x^H P A_c^-1 R C x        utils.py:252-361
     (deflation vectors and permutation were registered with the engine at setup)."""
-    eng = mg_solver.engine
-    if eng is None:
+    engs = _engines(mg_solver)
+    if not engs:
         raise EngineError("no GPU engine attached (run MG.setup first)")
     tol = params['function_params']['tol']
     n = mg_solver.ml.levels[level].A.shape[0]
@@ -221,7 +228,19 @@ def probe_batch(mg_solver, params, method, probes, level=0):
         mode = MODE_MLMC_SKIP if (mg_solver.skip_level and level == 0) else MODE_MLMC
     else:
         raise Exception("unknown method")
-    return eng.hutch_batch(mode, level, probes, tol, maxiter)
+    probes = np.asarray(probes)
+    nb = probes.shape[0]
+    if len(engs) == 1 or nb < 2 * 64:
+        return engs[0].hutch_batch(mode, level, probes, tol, maxiter)
+    # several engine handles = several HIP streams on the same GPU: the sub-batches overlap
+    # (MFMA-bound coarse kernels of one with HBM-bound fine kernels of the other)
+    from concurrent.futures import ThreadPoolExecutor
+    parts = np.array_split(np.arange(nb), len(engs))
+    with ThreadPoolExecutor(max_workers=len(engs)) as pool:
+        futs = [pool.submit(eng.hutch_batch, mode, level, probes[idx], tol, maxiter)
+                for eng, idx in zip(engs, parts) if len(idx)]
+        res = [f.result() for f in futs]
+    return tuple(np.concatenate([r[k] for r in res]) for k in range(3))
 
 
 def one_defl_Hutch_step(Af, Ac, mg_solver, params, method, nr_deflat_vctrs, Vx, Ux, i=0,

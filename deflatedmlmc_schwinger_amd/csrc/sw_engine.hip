@@ -117,6 +117,8 @@ struct sw_engine {
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
   bool lazy_sync = true;
+  int stencil_tile = 0;   // 0: automatic
+  int stencil_spw = 0;    // 0: automatic (4)
   // one Gram-Schmidt pass per Arnoldi step instead of two; every outer solve is then verified
   // against its TRUE residual and continued when the recurrence was optimistic
   bool cgs2 = false;
@@ -484,9 +486,13 @@ static int apply_coarsest(sw_engine* h, Hier& H, const cplx* X, cplx* Y, int nbp
   return launch_ell(h, H.cinv, 0, X, nullptr, Y, nbp, T_COARSEST);
 }
 
-static int stencil_spw(int L) {
-  // consecutive x-sites per wave: keep >= 8 workgroups per CU worth of blocks on 128^2
-  return 1;
+static int stencil_spw(sw_engine* h, int tile_w) {
+  // consecutive x-sites per wave (must divide the tile width)
+  // measured (profiles/r01_stencil_tiles.txt): one site per wave keeps the most independent
+  // loads in flight and beats the register sliding window (SPW 2/4/8) at every lattice size
+  int spw = h->stencil_spw > 0 ? h->stencil_spw : 1;
+  while (spw > 1 && tile_w % spw) spw >>= 1;
+  return spw;
 }
 
 // Y = A X (mode 0), Y = B - A X (mode 1) or Y = X + w (B - A X) (mode 2) at a level
@@ -500,22 +506,34 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     a.U1 = lv.U1;
     a.U2 = lv.U2;
     a.nbp = nbp;
-    a.sites_per_wave = stencil_spw(lv.L);
     a.w = w;
+    // x-tile: whole rows while three of them (2 KiB per site and 64-probe chunk) fit well
+    // inside a 4-MiB L2, otherwise 256-site (or 64-site) tiles: 3.6 -> 4.6 TB/s on 1024^2
+    a.tile_w = lv.L;
+    if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
+    if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0) a.tile_w = h->stencil_tile;
+    const int spw = stencil_spw(h, a.tile_w);
+    a.sites_per_wave = spw;
     const int V = lv.L * lv.L;
-    const int waves = V / a.sites_per_wave;
+    const int waves = V / spw;
     const int bpc = (waves + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
     const int nchunks = nbp / 64;
     LaunchScope ls(h, mode == 0 ? T_STENCIL : (mode == 1 ? T_STENCIL_RES : T_STENCIL_SM));
-    if (mode == 0)
-      hipLaunchKernelGGL((swk::k_stencil<0>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
-                         X, B, Y, a, bpc);
-    else if (mode == 1)
-      hipLaunchKernelGGL((swk::k_stencil<1>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
-                         X, B, Y, a, bpc);
-    else
-      hipLaunchKernelGGL((swk::k_stencil<2>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream,
-                         X, B, Y, a, bpc);
+#define ST_LAUNCH(MD, SP)                                                                       \
+  hipLaunchKernelGGL((swk::k_stencil<MD, SP>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, \
+                     X, B, Y, a, bpc)
+#define ST_MODE(SP)                    \
+  do {                                 \
+    if (mode == 0) ST_LAUNCH(0, SP);   \
+    else if (mode == 1) ST_LAUNCH(1, SP); \
+    else ST_LAUNCH(2, SP);             \
+  } while (0)
+    if (spw == 8) ST_MODE(8);
+    else if (spw == 4) ST_MODE(4);
+    else if (spw == 2) ST_MODE(2);
+    else ST_MODE(1);
+#undef ST_MODE
+#undef ST_LAUNCH
     KLAUNCH_CHECK();
     return 0;
   }
@@ -1280,6 +1298,16 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (!h || !name) return 1;
   if (std::strcmp(name, "use_mfma") == 0) {
     h->use_mfma = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "stencil_spw") == 0) {
+    const int v = (int)value;
+    if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return sw_fail(h, "stencil_spw must be 0,1,2,4,8");
+    h->stencil_spw = v;
+    return 0;
+  }
+  if (std::strcmp(name, "stencil_tile") == 0) {
+    h->stencil_tile = (int)value;
     return 0;
   }
   if (std::strcmp(name, "cgs2") == 0) {

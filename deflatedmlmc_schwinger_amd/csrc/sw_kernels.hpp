@@ -56,7 +56,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 
 // ------------------------------------------------------------------------------------------
 // Level-0 operator: U(1) Wilson-Schwinger stencil  A = S + m  (replaces the CSR
-// SpMV of multigrid.py:552-557 / matrix.py:21-29).  One wave = one lattice site x 64 probes.
+// SpMV of multigrid.py:552-557 / matrix.py:21-29).  One wave = SPW lattice sites x 64 probes.
 //   (S psi)(n) = 4 psi(n) - [ (1-s1) U1(n) psi(n+x) + (1+s1) U1*(n-x) psi(n-x)
 //                           + (1-s2) U2(n) psi(n+y) + (1+s2) U2*(n-y) psi(n-y) ]
 // MODE 0: Y = A X      MODE 1: Y = B - A X      MODE 2: Y = X + w (B - A X)  (one fused
@@ -70,6 +70,7 @@ struct StencilArgs {
   const cplx* U2;
   int nbp;
   int sites_per_wave;  // consecutive x-sites handled by one wave
+  int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
   cplx w;              // MODE 2 relaxation weight
 };
 
@@ -80,7 +81,7 @@ __device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
   return ((size_t)par * Vh + sh) * 2;
 }
 
-template <int MODE>
+template <int MODE, int SPW>
 __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X,
                                                       const cplx* __restrict__ B,
                                                       cplx* __restrict__ Y, StencilArgs a,
@@ -94,38 +95,45 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
   const int L = a.L;
   const int nbp = a.nbp;
   const size_t col = (size_t)chunk * 64 + lane;
-  const int spw = a.sites_per_wave;
-  const int site0 = __builtin_amdgcn_readfirstlane((sg * SW_WAVES_PER_BLOCK + wave) * spw);
+  const int site0 = __builtin_amdgcn_readfirstlane((sg * SW_WAVES_PER_BLOCK + wave) * SPW);
   if (site0 >= L * L) return;
-  const int y = site0 / L;
-  const int x0 = site0 % L;
+  // tile-major walk: tiles of tile_w x L sites, row by row inside a tile, so that the three
+  // lattice-row segments a block's neighbours live in (3 * tile_w * 2 KiB per 64-probe chunk)
+  // stay resident in the XCD's 4-MiB L2 on large lattices
+  const int tw = a.tile_w;
+  const int tile = site0 / (tw * L);
+  const int rem = site0 - tile * (tw * L);
+  const int y = rem / tw;
+  const int x0 = tile * tw + (rem - y * tw);
   const int yp = (y + 1 == L) ? 0 : y + 1;
   const int ym = (y == 0) ? L - 1 : y - 1;
   const cplx* Xc = X + col;
-  for (int s = 0; s < spw; ++s) {
-    const int x = x0 + s;  // spw divides L, so the run never leaves the row
+  // one wave = SPW consecutive x-sites of one lattice row x 64 probes; the x-neighbours slide
+  // through registers (left, centre, right), so a site costs 3 site-loads instead of 5
+  const int xl = (x0 == 0) ? L - 1 : x0 - 1;
+  size_t r_l = eo_row(xl, y, L, a.Vh);
+  size_t r_c = eo_row(x0, y, L, a.Vh);
+  cplx l0 = Xc[r_l * nbp], l1 = Xc[(r_l + 1) * nbp];
+  cplx c0 = Xc[r_c * nbp], c1 = Xc[(r_c + 1) * nbp];
+  cplx u1m = a.U1[y * L + xl];
+#pragma unroll
+  for (int s = 0; s < SPW; ++s) {
+    const int x = x0 + s;  // SPW divides tile_w, so the run never leaves the tile row
     const int xp = (x + 1 == L) ? 0 : x + 1;
-    const int xm = (x == 0) ? L - 1 : x - 1;
-    const size_t r_c = eo_row(x, y, L, a.Vh);
     const size_t r_xp = eo_row(xp, y, L, a.Vh);
-    const size_t r_xm = eo_row(xm, y, L, a.Vh);
     const size_t r_yp = eo_row(x, yp, L, a.Vh);
     const size_t r_ym = eo_row(x, ym, L, a.Vh);
-    // issue all ten loads before any use
-    const cplx c0 = Xc[r_c * nbp], c1 = Xc[(r_c + 1) * nbp];
     const cplx a0 = Xc[r_xp * nbp], a1 = Xc[(r_xp + 1) * nbp];
-    const cplx b0 = Xc[r_xm * nbp], b1 = Xc[(r_xm + 1) * nbp];
     const cplx d0 = Xc[r_yp * nbp], d1 = Xc[(r_yp + 1) * nbp];
     const cplx e0 = Xc[r_ym * nbp], e1 = Xc[(r_ym + 1) * nbp];
     const int n = y * L + x;
     const cplx u1 = a.U1[n];
-    const cplx u1m = a.U1[y * L + xm];
     const cplx u2 = a.U2[n];
     const cplx u2m = a.U2[ym * L + x];
     // +x: (1-s1) -> [t,-t], t = psi0 - psi1
     const cplx tx = cmul(u1, csub(a0, a1));
     // -x: (1+s1) -> [t, t], t = psi0 + psi1, link conj(U1(n-x))
-    const cplx txm = cmulc(u1m, cadd(b0, b1));
+    const cplx txm = cmulc(u1m, cadd(l0, l1));
     // +y: (1-s2) -> [t, -i t], t = psi0 + i psi1
     const cplx ty = cmul(u2, cadd(d0, cmuli(d1)));
     // -y: (1+s2) -> [t, i t], t = psi0 - i psi1, link conj(U2(n-y))
@@ -149,6 +157,11 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
     }
     Y[r_c * nbp + col] = o0;
     Y[(r_c + 1) * nbp + col] = o1;
+    // slide the window
+    l0 = c0; l1 = c1;
+    c0 = a0; c1 = a1;
+    r_c = r_xp;
+    u1m = u1;
   }
 }
 

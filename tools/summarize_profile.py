@@ -19,7 +19,7 @@ def main(out):
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        lines.append("rocprofv3 --kernel-trace --stats  (bench.py --steps 4 --warmup 1)")
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-large-stencil --no-cpu-baseline")
         lines.append("%-72s %7s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
         for r in rows[:24]:
             lines.append("%-72s %7d %12.3f %10.2f %6.2f" % (

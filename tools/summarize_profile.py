@@ -54,7 +54,7 @@ def main(out):
             wmb = w[1] / w[0] * 1024 / 1e6 if w else float("nan")
             lines.append("%-72s %12.2f %12.2f %12.2f" % (k, fmb, wmb, fmb + wmb))
             for tag in ("k_stencil<0>", "k_stencil<1>", "k_stencil<2>"):
-                if tag in k:
+                if tag[:-1] + "," in k or tag in k:
                     summary[tag] = {"hbm_bytes_per_launch": (fmb + wmb) * 1e6,
                                     "fetch_bytes_per_launch_corrected": fmb * 1e6,
                                     "write_bytes_per_launch": wmb * 1e6}

@@ -916,7 +916,10 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
         KLAUNCH_CHECK();
       }
       SWCHK(scale_to(h, ws.sc.scale, w, w, n, nbp));
-      if (outer && (done + j + 1 >= check_from || done + j + 1 >= maxiter)) {
+      // read the flag back from the hinted iteration on, at the end of the budget, and in any
+      // case every 8th iteration (a stale hint must never cost more than a few iterations)
+      if (outer && (done + j + 1 >= check_from || done + j + 1 >= maxiter ||
+                    ((done + j + 1) & 7) == 0)) {
         HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost,
                               h->stream));
         SWCHK(stream_sync(h));
@@ -965,7 +968,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     }
   }
   if (iters_total) *iters_total = done;
-  if (outer) h->sync_hint[hid_idx][level] = done;
+  if (outer) h->sync_hint[hid_idx][level] = converged ? done : 0;
   return 0;
 }
 
@@ -1084,6 +1087,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
   if (nlevels < 1 || nlevels > SW_MAX_LEVELS) return sw_fail(h, "nlevels %d out of range", nlevels);
   HIPCHK(hipSetDevice(h->device));
   Hier& H = h->hier[hid];
+  for (int l = 0; l < SW_MAX_LEVELS; ++l) h->sync_hint[hid][l] = 0;
   // release what the previous definition held
   for (int l = 0; l < SW_MAX_LEVELS; ++l) {
     Level& lv = H.lv[l];

@@ -134,7 +134,12 @@ class MG:
                 raise Exception("lattice extent %d not divisible by aggregate edge %d" % (Lf, agg))
             Lf //= agg
         t0 = time.time()
-        sh = _hier.solver_hierarchy(self.ml.levels[0].A, L, cfg, testvectors=testvectors)
+        if cfg.get("setup", "eigs") == "adaptive" and testvectors is None:
+            from . import setup_gpu
+            sh = setup_gpu.adaptive_solver_hierarchy(self.engines[0], self.ml.levels[0].A, lat, cfg,
+                                                     SOLVER_HID)
+        else:
+            sh = _hier.solver_hierarchy(self.ml.levels[0].A, L, cfg, testvectors=testvectors)
         nl = len(sh["A"])
         self.solver_hier = sh
         self.solver_weights = []
@@ -163,7 +168,8 @@ class MG:
         self._have_solver_hier = True
         self.solver_testvectors = sh["tv"]
         self.solver_info = {"levels": [a.shape[0] for a in sh["A"]],
-                            "setup_s": time.time() - t0, "cfg": cfg}
+                            "setup_s": time.time() - t0, "cfg": cfg,
+                            "setup_log": sh.get("setup_log")}
 
     # ------------------------------------------------------------------------------------
     def _need_engine(self):

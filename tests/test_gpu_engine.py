@@ -466,3 +466,32 @@ def test_argument_errors_surface_as_messages(p16):
         p16.eng.set_solver(1000, 0)
     with pytest.raises(EngineError, match="no probes uploaded|Hutchinson mode runs at level 0"):
         p16.eng.hutch_run(MODE_HUTCHINSON, 1, 1e-12, 10)
+
+
+def test_adaptive_gpu_setup_gives_a_working_hierarchy(p128):
+    """solver hierarchy from engine-side inverse iteration (no ARPACK / SuperLU):
+    same solve quality as the eigenvector-based one, per-probe parity unchanged."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    mg = p128.mg
+    base_iters = None
+    B = _rand((4, p128.A.shape[0]), 90)
+    X0, it0, _ = mg.solve_batch(0, B, 1e-12)
+    cfg = dict(hierarchy.DEFAULT_SOLVER_CFG, setup="adaptive", setup_sweeps=3, setup_tol=1e-1,
+               setup_maxiter=100)
+    try:
+        mg.upload_solver_hierarchy(cfg)
+        assert mg.solver_info["setup_log"] is not None
+        X1, it1, rr = mg.solve_batch(0, B, 1e-12)
+        assert rr.max() < 1e-12
+        assert it1.max() <= it0.max() + 6
+        assert _relerr(X1, X0) < 1e-8
+        np.random.seed(123456)
+        probes = utils.draw_probes(4, p128.A.shape[0])
+        ests, _, _ = mg.engine.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+        lu = p128.lu_solver(0)
+        for k in range(4):
+            ref = rp.hutch_probe(probes[k].astype(np.complex128), lu, p128.Ux,
+                                 p128.levels[0].Pperm.transpose())
+            assert abs(ests[k] - ref) / abs(ref) < 1e-10
+    finally:
+        mg.upload_solver_hierarchy(None)

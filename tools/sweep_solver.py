@@ -35,7 +35,7 @@ def main():
     eng.probes_upload(0, probes)
     last_key, tv = None, None
     for cfg in cfgs:
-        key = json.dumps(cfg["coarsening"])
+        key = json.dumps([cfg["coarsening"], cfg.get("setup"), cfg.get("setup_sweeps"), cfg.get("setup_tol"), cfg.get("setup_maxiter")])
         t0 = time.time()
         try:
             mg.upload_solver_hierarchy(cfg, testvectors=tv if key == last_key else None)
@@ -63,6 +63,7 @@ def main():
         launches = eng.launch_count()
         eng.set_profiling(False)
         print(json.dumps({"cfg": cfg, "levels": mg.solver_info["levels"], "ms": 1e3 * dt,
+                          "setup_log": mg.solver_info.get("setup_log"),
                           "probes_per_s": nb / dt, "iters": int(itf.max()), "setup_s": t_setup,
                           "buckets_ms": {k: round(v, 2) for k, v in b.items()},
                           "launches": launches, "e0": [ests[0].real, ests[0].imag]}), flush=True)

@@ -1,6 +1,7 @@
 """Example drivers with the reference's names (examples.py:13-51)."""
 import time
 
+from .cache import write_run_report
 from .matrix import loadMatrix
 from .stoch_trace import hutchinson, mlmc
 from .utils import print_post_results, trace_params_from_params
@@ -20,6 +21,7 @@ def _run(params, kind):
     t0 = time.time()
     result = estimator(A, trace_params)
     elapsed = time.time() - t0
+    write_run_report(result, kind, params, elapsed)
     return A, result, elapsed
 
 

@@ -10,6 +10,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
+from . import cache as _cache
 from . import hierarchy as _hier
 from .engine import Engine, EngineError
 from .hierarchy import LevelML, SimpleML  # noqa: F401  (re-exported, multigrid.py:26-48)
@@ -57,14 +58,47 @@ class MG:
         if params is None:
             raise Exception("setup needs the trace parameter dictionary")
         tv = params.get("mg_testvectors")
+        cdir = _cache.cache_dir(params)
+        ckey = None
+        if cdir and tv is None:
+            ckey = _cache.matrix_key(self._A0, {"dof": dof, "aggrs": aggrs, "levels": max_levels,
+                                                "acc": acc_eigvs})
+            hit = _cache.load(cdir, "mgtv", ckey)
+            if hit is not None:
+                tv = [hit["tv%d" % i] for i in range(max_levels - 1)]
+                ckey = None
         ml, cinv, used = _hier.reference_hierarchy(self._A0, dof, aggrs, max_levels, acc_eigvs,
                                                    params, testvectors=tv)
+        if ckey is not None:
+            _cache.save(cdir, "mgtv", ckey, {"tv%d" % i: np.asarray(v) for i, v in enumerate(used)})
+        self._cache_dir = cdir
         self.ml = ml
         self.coarsest_inv = cinv
         self.testvectors = used
         self.total_levels = len(ml.levels)
         self.A = ml.levels[0].A
         self._upload(params)
+
+    def setup_solver_only(self, solver_cfg=None, device=0, engines=1):
+        """Large synthetic lattices (BASELINE config 5): no reference (MLMC) hierarchy, only the
+        level-0 operator and the solver hierarchy, built without host ARPACK / SuperLU when
+        ``solver_cfg["setup"] == "adaptive"``.  Plain / deflated Hutchinson probes only."""
+        lat = _hier.detect_lattice(self._A0) if not isinstance(self._A0, tuple) else self._A0
+        if lat is None:
+            raise Exception("setup_solver_only needs a lattice operator")
+        self.lattice = lat
+        lev = LevelML()
+        lev.A = self._A0 if not isinstance(self._A0, tuple) else None
+        self.ml = SimpleML()
+        self.ml.levels.append(lev)
+        self.total_levels = 1
+        self.engines = [Engine(device) for _ in range(max(1, engines))]
+        self.engine = self.engines[0]
+        for eng in self.engines:
+            eng.hier_begin(REF_HID, 1)
+            eng.set_lattice(REF_HID, lat[0], lat[1], lat[2], lat[3])
+            eng.hier_end(REF_HID)
+        self.upload_solver_hierarchy(solver_cfg)
 
     def attach_hierarchy(self, ml, coarsest_inv, params):
         """Use an already built reference hierarchy (e.g. from a cache) instead of setup()."""
@@ -134,13 +168,28 @@ class MG:
                 raise Exception("lattice extent %d not divisible by aggregate edge %d" % (Lf, agg))
             Lf //= agg
         t0 = time.time()
+        cdir = getattr(self, "_cache_dir", None)
+        skey = None
+        if cdir and testvectors is None and self.ml.levels[0].A is not None:
+            skey = _cache.matrix_key(self.ml.levels[0].A, {"coarsening": cfg["coarsening"],
+                                                           "setup": cfg.get("setup", "eigs"),
+                                                           "eig_tol": cfg.get("eig_tol")})
+            hit = _cache.load(cdir, "solvertv", skey)
+            if hit is not None:
+                testvectors = [hit["tv%d" % i] for i in range(len(cfg["coarsening"]))]
+                skey = None
         if cfg.get("setup", "eigs") == "adaptive" and testvectors is None:
             from . import setup_gpu
-            sh = setup_gpu.adaptive_solver_hierarchy(self.engines[0], self.ml.levels[0].A, lat, cfg,
-                                                     SOLVER_HID)
+            A0 = self.ml.levels[0].A
+            if A0 is None:
+                A0 = _hier.wilson_from_links(lat[2], lat[3], lat[0]) + \
+                    lat[1] * sp.identity(2 * lat[0] * lat[0], dtype=np.complex128, format="csr")
+            sh = setup_gpu.adaptive_solver_hierarchy(self.engines[0], A0, lat, cfg, SOLVER_HID)
         else:
             sh = _hier.solver_hierarchy(self.ml.levels[0].A, L, cfg, testvectors=testvectors)
         nl = len(sh["A"])
+        if skey is not None:
+            _cache.save(cdir, "solvertv", skey, {"tv%d" % i: np.asarray(v) for i, v in enumerate(sh["tv"])})
         self.solver_hier = sh
         self.solver_weights = []
         for i in range(nl - 1):

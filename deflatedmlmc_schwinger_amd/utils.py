@@ -57,7 +57,7 @@ _COMMON_KEYS = ('max_nr_levels', 'nr_deflat_vctrs', 'defl_eigvs_tol_Hutch', 'acc
 _MLMC_KEYS = ('mlmc_deflat_vctrs', 'defl_eigvs_tol_MLMC', 'diff_lev_op_tol', 'defl_type',
               'coarsest_level_directly', 'mlmc_levels_to_skip')
 # build-only options (all optional; reference presets do not carry them)
-_BUILD_KEYS = ('batch', 'device', 'engines', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
+_BUILD_KEYS = ('batch', 'device', 'engines', 'cache_dir', 'report_path', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
                'solver_testvectors', 'deflation_eigenpairs', 'ref_cycle_post', 'ref_cycle_k',
                'verbose', 'probe_rounds_max')
 
@@ -154,8 +154,17 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
         if pre is not None:
             Sy, Vx = np.array(pre[0], dtype=float), np.array(pre[1], dtype=np.complex128)
         else:
-            Q = (lev0.g3 * A).tocsc()                                   # utils.py:137-140
-            Sy, Vx = eigsh(Q, k=nr_deflat_vctrs, which='LM', tol=tolx, sigma=0.0)
+            from . import cache as _cache
+            cdir = _cache.cache_dir(params)
+            ckey = _cache.matrix_key(A, {"k": nr_deflat_vctrs, "tol": tolx}) if cdir else None
+            hit = _cache.load(cdir, "defl", ckey) if cdir else None
+            if hit is not None:
+                Sy, Vx = hit["S"], hit["V"]
+            else:
+                Q = (lev0.g3 * A).tocsc()                               # utils.py:137-140
+                Sy, Vx = eigsh(Q, k=nr_deflat_vctrs, which='LM', tol=tolx, sigma=0.0)
+                if cdir:
+                    _cache.save(cdir, "defl", ckey, {"S": Sy, "V": Vx})
     else:
         mg_solver.solve_tol = params['diff_lev_op_tol']                 # utils.py:142-143
         Sy, Vx = eigsh(lop, k=nr_deflat_vctrs, which='LM', tol=tolx)

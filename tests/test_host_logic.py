@@ -252,3 +252,25 @@ def test_product_fails_loudly_without_gpu(A16):
                  sys_type='schwinger', params=tp)
     with pytest.raises(EngineError):
         MG(A16).solve(A16, np.ones(512), 1e-12)
+
+
+def test_setup_cache_roundtrip_and_run_report(tmp_path, A16):
+    from deflatedmlmc_schwinger_amd import cache
+    key = cache.matrix_key(A16, {"k": 8})
+    assert key == cache.matrix_key(A16, {"k": 8}) and key != cache.matrix_key(A16, {"k": 9})
+    assert cache.load(str(tmp_path), "defl", key) is None
+    cache.save(str(tmp_path), "defl", key, {"S": np.arange(3.0), "V": np.eye(3, dtype=complex)})
+    hit = cache.load(str(tmp_path), "defl", key)
+    assert np.array_equal(hit["S"], np.arange(3.0)) and hit["V"].dtype == np.complex128
+    # the reference hierarchy rebuilt from cached test vectors equals the first build
+    p = gateway.set_params('schwinger16')
+    p['function_tol'] = 1e-12
+    tp = utils.trace_params_from_params(p, "mlmc")
+    ml1, _, tv = hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], 3, 'low', tp)
+    ml2, _, _ = hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], 3, 'low', tp, testvectors=tv)
+    assert abs(ml1.levels[2].A - ml2.levels[2].A).max() == 0.0
+    rep = tmp_path / "runs.jsonl"
+    rec = cache.write_run_report({"trace": 1 + 2j, "std_dev": 3.0, "nr_ests": 9, "function_iters": 50},
+                                 "hutchinson", {"report_path": str(rep), "matrix": "x.mat"}, 2.0)
+    assert rec["probe_samples_per_s"] == 5.0
+    assert json.loads(rep.read_text().splitlines()[0])["trace"] == [1.0, 2.0]

@@ -44,13 +44,30 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
-    ap.add_argument("--cpu-probes", type=int, default=2)
+    ap.add_argument("--cpu-probes", type=int, default=6)
     ap.add_argument("--quiet-setup", action="store_true", default=True)
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    # Libraries (RCCL's version banner at communicator creation, for one) write to the process's
+    # stdout; the contract is ONE JSON line there.  Everything written to fd 1 during the run is
+    # sent to stderr, the JSON line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+    if line is not None:
+        os.write(1, (line + "\n").encode())
+    os.close(real_stdout)
+
+
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -62,12 +79,14 @@ def main():
     backend = os.environ.get("SW_DIST_BACKEND", "nccl")
     device_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device_index)
-    if world > 1:
+    if world > 1 or os.environ.get("SW_FORCE_PROCESS_GROUP"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         td.init_process_group(backend=backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
+    line_out = None
     from deflatedmlmc_schwinger_amd import dist as swdist
     from deflatedmlmc_schwinger_amd import gateway, matrix, utils
     from deflatedmlmc_schwinger_amd.engine import MODE_HUTCHINSON, ProbeStream
@@ -112,7 +131,7 @@ def main():
         for e in range(ne):
             engs[e].probes_upload_slot(s, 0, stream.rademacher(nb, n))
         stream.skip((world - 1 - rank) * ne * nb * n)
-    comm = swdist.TorchComm() if world > 1 else swdist.Comm()
+    comm = swdist.TorchComm() if td.is_initialized() else swdist.Comm()
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=ne)
 
@@ -145,7 +164,7 @@ def main():
     comm.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if td.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64,
                             device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -242,10 +261,11 @@ def main():
             out["stencil_roofline_1024"] = large_stencil_point()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes)
-        print(json.dumps(out))
-    if world > 1:
-        td.barrier()
+        line_out = json.dumps(out)
+    if td.is_initialized():
+        comm.barrier()
         td.destroy_process_group()
+    return line_out
 
 
 def large_stencil_point(L=1024, nb=64, reps=20):

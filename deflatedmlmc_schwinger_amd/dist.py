@@ -85,7 +85,11 @@ class TorchComm(Comm):
         return t.cpu().numpy()
 
     def barrier(self):
-        self._td.barrier()
+        if self._td.get_backend() == "nccl":
+            # name the device: an NCCL barrier otherwise guesses it from the rank
+            self._td.barrier(device_ids=[self._torch.cuda.current_device()])
+        else:
+            self._td.barrier()
 
 
 def default_comm():

@@ -41,11 +41,14 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
                     help="JSON solver-hierarchy override")
+    ap.add_argument("--workload", choices=["hutchinson", "mlmc"], default="hutchinson",
+                    help="hutchinson: deflated Hutchinson probes (BASELINE configs 2/4, the "
+                         "headline metric); mlmc: level-0 MLMC difference probes with level "
+                         "skipping, A0^-1 - P0 P1 A2^-1 R1 R0 (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
     ap.add_argument("--cpu-probes", type=int, default=6)
-    ap.add_argument("--quiet-setup", action="store_true", default=True)
     return ap.parse_args()
 
 
@@ -89,7 +92,7 @@ def run(args):
     line_out = None
     from deflatedmlmc_schwinger_amd import dist as swdist
     from deflatedmlmc_schwinger_amd import gateway, matrix, utils
-    from deflatedmlmc_schwinger_amd.engine import MODE_HUTCHINSON, ProbeStream
+    from deflatedmlmc_schwinger_amd.engine import MODE_HUTCHINSON, MODE_MLMC_SKIP, ProbeStream
     from deflatedmlmc_schwinger_amd.multigrid import MG, REF_HID
 
     # ---- setup (untimed): operands, hierarchies, deflation vectors --------------------
@@ -102,7 +105,8 @@ def run(args):
     if args.cfg:
         params['solver_cfg'] = json.loads(args.cfg)
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
-    tp = utils.trace_params_from_params(params, "hutchinson")
+    tp = utils.trace_params_from_params(params, "mlmc" if args.workload == "mlmc" else "hutchinson")
+    run_mode = MODE_MLMC_SKIP if args.workload == "mlmc" else MODE_HUTCHINSON
     t_setup = time.time()
     mg = MG(A)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -137,7 +141,7 @@ def run(args):
 
     def run_one(e, s):
         engs[e].probes_select(s)
-        engs[e].hutch_run(MODE_HUTCHINSON, 0, args.tol, maxiter)
+        engs[e].hutch_run(run_mode, 0, args.tol, maxiter)
         return engs[e].hutch_fetch()
 
     def step(s):
@@ -169,6 +173,18 @@ def run(args):
                             device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- the same steps through the host-buffer boundary (probe upload over PCIe included) ----
+    host_batches = [[ProbeStream(7 + e).rademacher(nb, n) for e in range(ne)]]
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, args.warmup + args.steps):
+        for e in range(ne):
+            engs[e].probes_upload_slot(s, 0, host_batches[0][e])
+        step(s)
+    torch.cuda.synchronize()
+    elapsed_pcie = time.perf_counter() - t0
 
     # ---- instrumented step: HIP events around every launch, on the engine stream ----------
     eng.set_profiling(True)
@@ -223,13 +239,15 @@ def run(args):
                       key=lambda r: r["step_ms"], default=None)
         bytes0 = algo["k_stencil<0>"][1]
         out = {
-            "metric": "hutchinson_probe_samples_per_sec_schwinger128",
+            "metric": "hutchinson_probe_samples_per_sec_schwinger128" if args.workload == "hutchinson"
+                      else "mlmc_level0_difference_probe_samples_per_sec_schwinger128",
             "value": world * ne * args.steps * nb / elapsed,
             "unit": "probe-samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "value_pcie_inclusive_this_rank": ne * args.steps * nb / elapsed_pcie,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -239,7 +257,11 @@ def run(args):
             "config": {
                 "workload": "schwinger128, %d x %d probes/GPU/step (%d concurrent multi-RHS batches "
                             "of %d on separate HIP streams), deflated Hutchinson (k=8, Pperm shift "
-                            "512), fp64, tol %.0e" % (ne, nb, ne, nb, args.tol),
+                            "512), fp64, tol %.0e" % (ne, nb, ne, nb, args.tol)
+                            if args.workload == "hutchinson" else
+                            "schwinger128, %d x %d MLMC level-0 difference probes/GPU/step "
+                            "(A0^-1 - P0 P1 A2^-1 R1 R0, reference hierarchy 32768/8192/2048/512, "
+                            "level skipping), fp64, tol %.0e" % (ne, nb, args.tol),
                 "probes_per_step_per_gpu": ne * nb,
                 "streams_per_gpu": ne,
                 "solver": mg.solver_info,
@@ -259,7 +281,7 @@ def run(args):
         }
         if not args.no_large_stencil:
             out["stencil_roofline_1024"] = large_stencil_point()
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "hutchinson":
             out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes)
         line_out = json.dumps(out)
     if td.is_initialized():

@@ -112,6 +112,7 @@ struct sw_engine {
   int restart = 24;
   int solver_hid = 0;
   bool use_mfma = true;
+  bool mfma_ops = true;   // MFMA block-row kernel also for block-structured level operators
   int mfma_tiles = 4;
   // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
@@ -369,7 +370,6 @@ static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, cons
   if (n % 16) return 0;
   const int RT = n / 16;
   std::vector<std::vector<int>> groups(RT);
-  size_t total = 0;
   int KS = 0;
   for (int rt = 0; rt < RT; ++rt) {
     std::vector<int>& g = groups[rt];
@@ -378,7 +378,6 @@ static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, cons
     std::sort(g.begin(), g.end());
     g.erase(std::unique(g.begin(), g.end()), g.end());
     KS = std::max(KS, (int)g.size());
-    total += g.size();
   }
   if (KS == 0) return 0;
   KS += KS & 1;   // the kernel's two-stage pipeline wants an even number of k-steps
@@ -447,7 +446,8 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
 static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B,
                       cplx* Y, int nbp, int cat, cplx w = cplx{0.0, 0.0}) {
   if (!op.set) return sw_fail(h, "operator not set");
-  if (op.bsr_KS > 0 && (mode == 0 || mode == 1 || mode == 3) && h->use_mfma)
+  if (op.bsr_KS > 0 && (mode == 0 || mode == 1 || mode == 3) && h->use_mfma &&
+      (cat == T_COARSEST || h->mfma_ops))
     return launch_bsr(h, op, mode, X, B, Y, nbp, cat, w);
   dim3 grid((op.ngroups + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
   LaunchScope ls(h, cat);
@@ -455,16 +455,16 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   case GG:                                                                                      \
     if (mode == 0)                                                                              \
       hipLaunchKernelGGL((swk::k_ell<GG, 0>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
     else if (mode == 1)                                                                         \
       hipLaunchKernelGGL((swk::k_ell<GG, 1>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
     else if (mode == 2)                                                                         \
       hipLaunchKernelGGL((swk::k_ell<GG, 2>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
     else                                                                                        \
       hipLaunchKernelGGL((swk::k_ell<GG, 3>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, (const int*)nullptr, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
     break;
   switch (op.G) {
     ELL_CASE(1)
@@ -513,7 +513,6 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
     if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0) a.tile_w = h->stencil_tile;
     const int spw = stencil_spw(h, a.tile_w);
-    a.sites_per_wave = spw;
     const int V = lv.L * lv.L;
     const int waves = V / spw;
     const int bpc = (waves + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
@@ -1324,6 +1323,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "lazy_sync") == 0) {
     h->lazy_sync = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "mfma_ops") == 0) {
+    h->mfma_ops = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "mfma_tiles") == 0) {

@@ -43,9 +43,8 @@ __device__ __forceinline__ void cfmac(cplx& acc, cplx a, cplx b) {
   acc.y = fma(a.x, b.y, acc.y);
   acc.y = fma(-a.y, b.x, acc.y);
 }
-// i*a, -i*a
+// i*a
 __device__ __forceinline__ cplx cmuli(cplx a) { return cmake(-a.y, a.x); }
-__device__ __forceinline__ cplx cmulmi(cplx a) { return cmake(a.y, -a.x); }
 
 // Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH, Workgroup dispatch); this
 // bijective remap hands each XCD one contiguous range of logical blocks so that neighbouring
@@ -69,7 +68,6 @@ struct StencilArgs {
   const cplx* U1; // [L*L] site index y*L+x
   const cplx* U2;
   int nbp;
-  int sites_per_wave;  // consecutive x-sites handled by one wave
   int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
   cplx w;              // MODE 2 relaxation weight
 };
@@ -177,13 +175,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
 template <int G, int MODE>
 __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
                                                   const cplx* __restrict__ vals, int K,
-                                                  int ngroups, const int* __restrict__ rowmap,
+                                                  int ngroups,
                                                   const cplx* __restrict__ X,
                                                   const cplx* __restrict__ B,
                                                   cplx* __restrict__ Y, int nbp, cplx w) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  const int grp = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + wave);
+  const int bx = xcd_remap(blockIdx.x, gridDim.x);   // contiguous row band per XCD (L2 reuse)
+  const int grp = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + wave);
   if (grp >= ngroups) return;
   const size_t col = (size_t)blockIdx.y * 64 + lane;
   const int* c = cols + (size_t)grp * K;
@@ -201,8 +200,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    // rowmap (optional): output row of logical row grp*G+g (level-0 even-odd permutation)
-    const size_t row = rowmap ? (size_t)rowmap[(size_t)grp * G + g] : (size_t)grp * G + g;
+    const size_t row = (size_t)grp * G + g;
     cplx o = acc[g];
     if (MODE == 1) o = csub(B[row * nbp + col], o);
     if (MODE == 2) o = cadd(B[row * nbp + col], o);
@@ -247,7 +245,11 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   // the X rows they share (all of them for a dense operator, the common neighbours for a
   // block stencil) are served once from L2 and then from the CU's L1
   const int lane = threadIdx.x & 63;
-  const int rt = __builtin_amdgcn_readfirstlane(blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  // XCD-aware: consecutive block ids are dealt round-robin over the 8 XCDs; remapping hands each
+  // XCD one contiguous band of row tiles, so the X rows its tiles share (lattice neighbours of a
+  // block stencil) are fetched into that XCD's L2 once instead of into all eight
+  const int bx = xcd_remap(blockIdx.x, gridDim.x);
+  const int rt = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (rt >= RT) return;
   const int c0 = blockIdx.y * (16 * NT);            // first real column of this chunk
   const cplx* a = Ap + (size_t)rt * KS * 64 + lane;

@@ -44,6 +44,7 @@ enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER
                 T_STENCIL_SM,   // k_stencil<2>  Y = X + w (B - A X)
                 T_MFMA_DENSE,   // k_bsr_mfma on the dense coarsest inverse
                 T_MFMA_OP,      // k_bsr_mfma on a block-structured level operator
+                T_STENCIL_SM2,  // k_stencil_2step: two fused smoother steps
                 T_NCAT };
 // classes >= T_STENCIL are folded into the mvm / coarsest buckets by sw_timers and reported
 // separately by sw_kernel_stats
@@ -118,6 +119,9 @@ struct sw_engine {
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
   bool lazy_sync = true;
+  // pairs of level-0 polynomial steps in one stencil launch (k_stencil_2step).  Measured at parity
+  // with two separate launches (the 36 L2-served loads per site make it L2-bound), so off by default
+  bool fuse_smoother = false;
   int stencil_tile = 0;   // 0: automatic
   int stencil_spw = 0;    // 0: automatic (4)
   // one Gram-Schmidt pass per Arnoldi step instead of two; every outer solve is then verified
@@ -756,6 +760,30 @@ static int mr_smooth(sw_engine* h, Level& lv, cplx* X, cplx* R, int nu, int nbp)
   return 0;
 }
 
+// two fused Richardson steps on the stencil level:  Y = S_w2(S_w1(X))
+static int apply_stencil_2step(sw_engine* h, Level& lv, const cplx* X, const cplx* B, cplx* Y, int nbp,
+                               cplx w1, cplx w2) {
+  swk::StencilArgs a;
+  a.L = lv.L;
+  a.Vh = lv.L * lv.L / 2;
+  a.diag = 4.0 + lv.mass;
+  a.U1 = lv.U1;
+  a.U2 = lv.U2;
+  a.nbp = nbp;
+  a.w = w1;
+  a.tile_w = lv.L;
+  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0) a.tile_w = h->stencil_tile;
+  const int V = lv.L * lv.L;
+  const int bpc = (V + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const int nchunks = nbp / 64;
+  LaunchScope ls(h, T_STENCIL_SM2);
+  hipLaunchKernelGGL(swk::k_stencil_2step, dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, X, B, Y,
+                     a, w2, bpc);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
 // n fixed-weight Richardson steps  x <- x + w_k (B - A x), ping-ponging between `cur`
 // (holding x on entry, ignored when from_zero) and `other`; *result = buffer with the answer
 static int rich_steps(sw_engine* h, Level& lv, const cplx* Bin, cplx* cur, cplx* other,
@@ -770,8 +798,15 @@ static int rich_steps(sw_engine* h, Level& lv, const cplx* Bin, cplx* cur, cplx*
     KLAUNCH_CHECK();
     k = 1;
   }
-  for (; k < w.size(); ++k) {
-    SWCHK(apply_op(h, lv, 2, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()}));
+  while (k < w.size()) {
+    if (lv.stencil && h->fuse_smoother && lv.L >= 4 && k + 1 < w.size()) {
+      SWCHK(apply_stencil_2step(h, lv, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()},
+                                cplx{w[k + 1].real(), w[k + 1].imag()}));
+      k += 2;
+    } else {
+      SWCHK(apply_op(h, lv, 2, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()}));
+      k += 1;
+    }
     std::swap(cur, other);
   }
   *result = cur;
@@ -843,9 +878,12 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
     SWCHK(launch_ell(h, lv.R, 0, Bin, nullptr, lc.b, nbp, T_R));
   }
   SWCHK(coarse_correction(h, H, l, nbp));
-  // place the prolongated iterate so that npost ping-pong steps end in Xout
-  cplx* start = (npost % 2 == 0) ? Xout : lv.t;
-  cplx* other = (npost % 2 == 0) ? lv.t : Xout;
+  // place the prolongated iterate so that the ping-pong launches of the post-smoother end in Xout
+  // (pairs of steps are one launch on the stencil level)
+  const bool fused = lv.stencil && h->fuse_smoother && lv.L >= 4;
+  const size_t nlaunch = fused ? (npost / 2 + npost % 2) : npost;
+  cplx* start = (nlaunch % 2 == 0) ? Xout : lv.t;
+  cplx* other = (nlaunch % 2 == 0) ? lv.t : Xout;
   if (xpre) SWCHK(launch_ell(h, lv.P, 2, lc.x, xpre, start, nbp, T_P));
   else SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, start, nbp, T_P));
   cplx* res = start;
@@ -1323,6 +1361,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "lazy_sync") == 0) {
     h->lazy_sync = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "fuse_smoother") == 0) {
+    h->fuse_smoother = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "mfma_ops") == 0) {
@@ -1831,7 +1873,8 @@ int sw_timers(sw_engine* h, double t[8]) {
   if (!h || !t) return 1;
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
-  t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP];
+  t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP] +
+              h->tacc[T_STENCIL_SM2];
   t[T_COARSEST] += h->tacc[T_MFMA_DENSE];
   return 0;
 }

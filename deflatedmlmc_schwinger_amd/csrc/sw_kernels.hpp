@@ -164,6 +164,111 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
 }
 
 // ------------------------------------------------------------------------------------------
+// Two fused smoother steps (temporal blocking):  Y = S_w2(S_w1(X)),  S_w(x) = x + w (B - A x).
+// The second step needs S_w1(X) on the five stencil points, which are recomputed in registers
+// from the 13-point neighbourhood of X and the 5-point neighbourhood of B (all L2-served), so
+// two polynomial steps cost 3 HBM vector passes instead of 6.  One wave = one site x 64 probes.
+// ------------------------------------------------------------------------------------------
+struct Site2 {
+  cplx s0, s1;
+};
+
+__device__ __forceinline__ Site2 ld_site(const cplx* __restrict__ base, int x, int y, int L, int Vh,
+                                         int nbp) {
+  const size_t r = eo_row(x, y, L, Vh);
+  Site2 v;
+  v.s0 = base[r * nbp];
+  v.s1 = base[(r + 1) * nbp];
+  return v;
+}
+
+// (A psi)(m) from psi(m) and its four neighbours; u1 = U1(m), u1m = U1(m-x), u2 = U2(m), u2m = U2(m-y)
+__device__ __forceinline__ Site2 wilson_site(double diag, Site2 c, Site2 xp, Site2 xm, Site2 yp,
+                                             Site2 ym, cplx u1, cplx u1m, cplx u2, cplx u2m) {
+  const cplx tx = cmul(u1, csub(xp.s0, xp.s1));
+  const cplx txm = cmulc(u1m, cadd(xm.s0, xm.s1));
+  const cplx ty = cmul(u2, cadd(yp.s0, cmuli(yp.s1)));
+  const cplx tym = cmulc(u2m, csub(ym.s0, cmuli(ym.s1)));
+  const cplx h0 = cadd(cadd(tx, txm), cadd(ty, tym));
+  const cplx h1 = cadd(csub(txm, tx), cmuli(csub(tym, ty)));
+  Site2 o;
+  o.s0 = cmake(fma(diag, c.s0.x, -h0.x), fma(diag, c.s0.y, -h0.y));
+  o.s1 = cmake(fma(diag, c.s1.x, -h1.x), fma(diag, c.s1.y, -h1.y));
+  return o;
+}
+
+// x + w (b - Ax)
+__device__ __forceinline__ Site2 relax_site(Site2 x, Site2 b, Site2 ax, cplx w) {
+  Site2 o = x;
+  cfma(o.s0, w, csub(b.s0, ax.s0));
+  cfma(o.s1, w, csub(b.s1, ax.s1));
+  return o;
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step(const cplx* __restrict__ X,
+                                                            const cplx* __restrict__ B,
+                                                            cplx* __restrict__ Y, StencilArgs a,
+                                                            cplx w2, int blocks_per_chunk) {
+  const int nblk = gridDim.x;
+  const int bb = xcd_remap(blockIdx.x, nblk);
+  const int chunk = bb / blocks_per_chunk;
+  const int sg = bb % blocks_per_chunk;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
+  const size_t col = (size_t)chunk * 64 + lane;
+  const int site0 = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + wave);
+  if (site0 >= L * L) return;
+  const int tw = a.tile_w;
+  const int tile = site0 / (tw * L);
+  const int rem = site0 - tile * (tw * L);
+  const int y = rem / tw;
+  const int x = tile * tw + (rem - y * tw);
+  const int xp = (x + 1 == L) ? 0 : x + 1, xm = (x == 0) ? L - 1 : x - 1;
+  const int yp = (y + 1 == L) ? 0 : y + 1, ym = (y == 0) ? L - 1 : y - 1;
+  const int xpp = (xp + 1 == L) ? 0 : xp + 1, xmm = (xm == 0) ? L - 1 : xm - 1;
+  const int ypp = (yp + 1 == L) ? 0 : yp + 1, ymm = (ym == 0) ? L - 1 : ym - 1;
+  const cplx* Xc = X + col;
+  const cplx* Bc = B + col;
+  // 13-point neighbourhood of X, 5-point neighbourhood of B
+  const Site2 x00 = ld_site(Xc, x, y, L, Vh, nbp);
+  const Site2 xP0 = ld_site(Xc, xp, y, L, Vh, nbp), xM0 = ld_site(Xc, xm, y, L, Vh, nbp);
+  const Site2 x0P = ld_site(Xc, x, yp, L, Vh, nbp), x0M = ld_site(Xc, x, ym, L, Vh, nbp);
+  const Site2 xPP = ld_site(Xc, xp, yp, L, Vh, nbp), xPM = ld_site(Xc, xp, ym, L, Vh, nbp);
+  const Site2 xMP = ld_site(Xc, xm, yp, L, Vh, nbp), xMM = ld_site(Xc, xm, ym, L, Vh, nbp);
+  const Site2 x20 = ld_site(Xc, xpp, y, L, Vh, nbp), xm20 = ld_site(Xc, xmm, y, L, Vh, nbp);
+  const Site2 x02 = ld_site(Xc, x, ypp, L, Vh, nbp), x0m2 = ld_site(Xc, x, ymm, L, Vh, nbp);
+  const Site2 b00 = ld_site(Bc, x, y, L, Vh, nbp);
+  const Site2 bP0 = ld_site(Bc, xp, y, L, Vh, nbp), bM0 = ld_site(Bc, xm, y, L, Vh, nbp);
+  const Site2 b0P = ld_site(Bc, x, yp, L, Vh, nbp), b0M = ld_site(Bc, x, ym, L, Vh, nbp);
+  const cplx* U1 = a.U1;
+  const cplx* U2 = a.U2;
+  const double d = a.diag;
+  const cplx w1 = a.w;
+#define SW_U1(xx, yy) U1[(yy) * L + (xx)]
+#define SW_U2(xx, yy) U2[(yy) * L + (xx)]
+  // first step on the five stencil points
+  const Site2 s00 = relax_site(x00, b00,
+      wilson_site(d, x00, xP0, xM0, x0P, x0M, SW_U1(x, y), SW_U1(xm, y), SW_U2(x, y), SW_U2(x, ym)), w1);
+  const Site2 sP0 = relax_site(xP0, bP0,
+      wilson_site(d, xP0, x20, x00, xPP, xPM, SW_U1(xp, y), SW_U1(x, y), SW_U2(xp, y), SW_U2(xp, ym)), w1);
+  const Site2 sM0 = relax_site(xM0, bM0,
+      wilson_site(d, xM0, x00, xm20, xMP, xMM, SW_U1(xm, y), SW_U1(xmm, y), SW_U2(xm, y), SW_U2(xm, ym)), w1);
+  const Site2 s0P = relax_site(x0P, b0P,
+      wilson_site(d, x0P, xPP, xMP, x02, x00, SW_U1(x, yp), SW_U1(xm, yp), SW_U2(x, yp), SW_U2(x, y)), w1);
+  const Site2 s0M = relax_site(x0M, b0M,
+      wilson_site(d, x0M, xPM, xMM, x00, x0m2, SW_U1(x, ym), SW_U1(xm, ym), SW_U2(x, ym), SW_U2(x, ymm)), w1);
+  // second step at the centre
+  const Site2 out = relax_site(s00, b00,
+      wilson_site(d, s00, sP0, sM0, s0P, s0M, SW_U1(x, y), SW_U1(xm, y), SW_U2(x, y), SW_U2(x, ym)), w2);
+#undef SW_U1
+#undef SW_U2
+  const size_t r = eo_row(x, y, L, Vh);
+  Y[r * nbp + col] = out.s0;
+  Y[(r + 1) * nbp + col] = out.s1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Grouped-ELL operator: coarse operators A_l, prolongators P_l, restrictors R_l = P_l^H, the
 // dense coarsest inverse and the MLMC rhs maps.  G consecutive rows share one list of K column
 // indices (the dense-block structure of SURVEY 3.4); one wave = one row group x 64 probes, each

@@ -148,6 +148,7 @@ int sw_timers_reset(sw_engine* h);
 #define SW_KCLASS_STENCIL_SM 10     /* k_stencil<2>  Y = X + w (B - A X)           */
 #define SW_KCLASS_MFMA_DENSE 11     /* k_bsr_mfma, dense coarsest inverse          */
 #define SW_KCLASS_MFMA_OP 12        /* k_bsr_mfma, block-structured level operator */
+#define SW_KCLASS_STENCIL_SM2 13     /* k_stencil_2step, two fused smoother steps   */
 int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);
 /* Kernel launches issued since the last reset (for launch-bound analysis). */
 int sw_launch_count(sw_engine* h, int64_t* n);

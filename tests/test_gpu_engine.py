@@ -495,3 +495,24 @@ def test_adaptive_gpu_setup_gives_a_working_hierarchy(p128):
             assert abs(ests[k] - ref) / abs(ref) < 1e-10
     finally:
         mg.upload_solver_hierarchy(None)
+
+
+def test_fused_two_step_smoother_kernel_matches_model(p16, p128):
+    """opt-in temporal blocking of the level-0 polynomial smoother (k_stencil_2step): same cycle
+    as the NumPy model, for an odd and an even number of steps."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    for p in (p16, p128):
+        for nu in (7, 4):
+            cfg = dict(hierarchy.DEFAULT_SOLVER_CFG, cycle=[(0, nu, 0), (0, 3, 0)])
+            try:
+                p.mg.upload_solver_hierarchy(cfg, testvectors=p.mg.solver_testvectors)
+                p.eng.set_option("fuse_smoother", 1)
+                sh = p.mg.solver_hier
+                B = _rand((sh["A"][0].shape[0], 3), 46 + nu)
+                ref = em.cycle(sh["A"], sh["P"], sh["coarsest_inv"], [tuple(c) for c in cfg["cycle"]],
+                               0, B, weights=p.mg.solver_weights)
+                X = p.eng.vcycle(SOLVER_HID, 0, B.T.copy())
+                assert _relerr(X.T, ref) < 1e-10
+            finally:
+                p.eng.set_option("fuse_smoother", 0)
+                p.mg.upload_solver_hierarchy(None, testvectors=p.mg.solver_testvectors)

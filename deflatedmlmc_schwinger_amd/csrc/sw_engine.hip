@@ -122,6 +122,7 @@ struct sw_engine {
   // pairs of level-0 polynomial steps in one stencil launch (k_stencil_2step).  Measured at parity
   // with two separate launches (the 36 L2-served loads per site make it L2-bound), so off by default
   bool fuse_smoother = false;
+  bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
   int stencil_spw = 0;    // 0: automatic (4)
   // one Gram-Schmidt pass per Arnoldi step instead of two; every outer solve is then verified
@@ -511,6 +512,7 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     a.U2 = lv.U2;
     a.nbp = nbp;
     a.w = w;
+    a.nt_store = h->stencil_nt ? 1 : 0;
     // x-tile: whole rows while three of them (2 KiB per site and 64-probe chunk) fit well
     // inside a 4-MiB L2, otherwise 256-site (or 64-site) tiles: 3.6 -> 4.6 TB/s on 1024^2
     a.tile_w = lv.L;
@@ -771,6 +773,7 @@ static int apply_stencil_2step(sw_engine* h, Level& lv, const cplx* X, const cpl
   a.U2 = lv.U2;
   a.nbp = nbp;
   a.w = w1;
+  a.nt_store = 0;
   a.tile_w = lv.L;
   if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
   if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0) a.tile_w = h->stencil_tile;
@@ -1339,6 +1342,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (!h || !name) return 1;
   if (std::strcmp(name, "use_mfma") == 0) {
     h->use_mfma = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "stencil_nt") == 0) {
+    h->stencil_nt = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "stencil_spw") == 0) {

@@ -70,6 +70,7 @@ struct StencilArgs {
   int nbp;
   int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
   cplx w;              // MODE 2 relaxation weight
+  int nt_store;        // non-temporal output stores
 };
 
 __device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
@@ -153,8 +154,16 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
       o0 = t0;
       o1 = t1;
     }
-    Y[r_c * nbp + col] = o0;
-    Y[(r_c + 1) * nbp + col] = o1;
+    if (a.nt_store) {
+      // streaming output: keep it from displacing the neighbour rows held in L2
+      __builtin_nontemporal_store(o0.x, &Y[r_c * nbp + col].x);
+      __builtin_nontemporal_store(o0.y, &Y[r_c * nbp + col].y);
+      __builtin_nontemporal_store(o1.x, &Y[(r_c + 1) * nbp + col].x);
+      __builtin_nontemporal_store(o1.y, &Y[(r_c + 1) * nbp + col].y);
+    } else {
+      Y[r_c * nbp + col] = o0;
+      Y[(r_c + 1) * nbp + col] = o1;
+    }
     // slide the window
     l0 = c0; l1 = c1;
     c0 = a0; c1 = a1;

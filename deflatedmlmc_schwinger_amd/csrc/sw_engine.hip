@@ -122,6 +122,7 @@ struct sw_engine {
   // pairs of level-0 polynomial steps in one stencil launch (k_stencil_2step).  Measured at parity
   // with two separate launches (the 36 L2-served loads per site make it L2-bound), so off by default
   bool fuse_smoother = false;
+  bool fuse_lds = true;   // with fuse_smoother: the LDS-staged tile kernel instead of the register one
   bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
   int stencil_spw = 0;    // 0: automatic (4)
@@ -778,11 +779,19 @@ static int apply_stencil_2step(sw_engine* h, Level& lv, const cplx* X, const cpl
   if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
   if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0) a.tile_w = h->stencil_tile;
   const int V = lv.L * lv.L;
-  const int bpc = (V + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const int nchunks = nbp / 64;
   LaunchScope ls(h, T_STENCIL_SM2);
-  hipLaunchKernelGGL(swk::k_stencil_2step, dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, X, B, Y,
-                     a, w2, bpc);
+  if (h->fuse_lds && lv.L % 8 == 0 && lv.L >= 16) {
+    // LDS-staged halo tiles: 8 x 8 sites x 8 probes per workgroup
+    const int tiles = (lv.L / 8) * (lv.L / 8);
+    const int groups = nbp / 8;
+    hipLaunchKernelGGL(swk::k_stencil_2step_lds, dim3(tiles * groups), dim3(SW_BLOCK), 0, h->stream,
+                       X, B, Y, a, w2, tiles);
+  } else {
+    const int bpc = (V + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+    const int nchunks = nbp / 64;
+    hipLaunchKernelGGL(swk::k_stencil_2step, dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, X, B,
+                       Y, a, w2, bpc);
+  }
   KLAUNCH_CHECK();
   return 0;
 }
@@ -1368,6 +1377,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "lazy_sync") == 0) {
     h->lazy_sync = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "fuse_lds") == 0) {
+    h->fuse_lds = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "fuse_smoother") == 0) {

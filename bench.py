@@ -41,10 +41,14 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
                     help="JSON solver-hierarchy override")
-    ap.add_argument("--workload", choices=["hutchinson", "mlmc"], default="hutchinson",
+    ap.add_argument("--lattice", type=int, default=1024, help="extent of the synthetic lattice "
+                    "(--workload synthetic only)")
+    ap.add_argument("--workload", choices=["hutchinson", "mlmc", "synthetic"], default="hutchinson",
                     help="hutchinson: deflated Hutchinson probes (BASELINE configs 2/4, the "
                          "headline metric); mlmc: level-0 MLMC difference probes with level "
-                         "skipping, A0^-1 - P0 P1 A2^-1 R1 R0 (config 3)")
+                         "skipping, A0^-1 - P0 P1 A2^-1 R1 R0 (config 3); synthetic: plain Hutchinson "
+                         "probes on a synthetic random-gauge --lattice^2 configuration with the "
+                         "GPU-side adaptive setup (config 5; use --nb 64 --streams 1 at 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
@@ -104,20 +108,41 @@ def run(args):
     params['engines'] = max(1, args.streams)
     if args.cfg:
         params['solver_cfg'] = json.loads(args.cfg)
-    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
-    tp = utils.trace_params_from_params(params, "mlmc" if args.workload == "mlmc" else "hutchinson")
+    synthetic = args.workload == "synthetic"
     run_mode = MODE_MLMC_SKIP if args.workload == "mlmc" else MODE_HUTCHINSON
     t_setup = time.time()
-    mg = MG(A)
-    with contextlib.redirect_stdout(io.StringIO()):
-        mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
-                 acc_eigvs=tp['accuracy_mg_eigvs'], sys_type=tp['problem_name'], params=tp)
-        Ux, tr1 = utils.deflation_pre_computations(A, tp['nr_deflat_vctrs'],
-                                                   tp['defl_eigvs_tol_Hutch'], "hutchinson",
-                                                   mg.timer, tp, mg)
+    if synthetic:
+        # BASELINE config 5: sigma = 0.204 <-> mean plaquette ~0.92, m = -0.05
+        Ls = args.lattice
+        U1s, U2s = matrix.synthetic_links(Ls, 0.204, 2024)
+        depth = [[4, 8], [4, 8], [4, 8]] if Ls >= 1024 else ([[4, 8], [4, 8], [2, 8]] if Ls >= 512
+                                                              else [[4, 8], [4, 8]])
+        cyc = [[0, 7, 3]] * (len(depth) - 1) + [[0, 7, 0]]
+        scfg = {"coarsening": depth, "cycle": cyc, "restart": 8, "setup": "adaptive",
+                "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 100}
+        if args.cfg:
+            scfg = json.loads(args.cfg)
+        mg = MG((Ls, -0.05, U1s, U2s))
+        with contextlib.redirect_stdout(io.StringIO()):
+            mg.setup_solver_only(scfg, device=device_index, engines=max(1, args.streams))
+        tr1 = 0.0
+        tp = None
+        A = None
+        n_unknowns = 2 * Ls * Ls
+    else:
+        A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+        tp = utils.trace_params_from_params(params, "mlmc" if args.workload == "mlmc" else "hutchinson")
+        mg = MG(A)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+                     acc_eigvs=tp['accuracy_mg_eigvs'], sys_type=tp['problem_name'], params=tp)
+            Ux, tr1 = utils.deflation_pre_computations(A, tp['nr_deflat_vctrs'],
+                                                       tp['defl_eigvs_tol_Hutch'], "hutchinson",
+                                                       mg.timer, tp, mg)
+        n_unknowns = A.shape[0]
     t_setup = time.time() - t_setup
     eng = mg.engine
-    n = A.shape[0]
+    n = n_unknowns
     L = mg.lattice[0]
     V = L * L
     nb = args.nb
@@ -215,7 +240,11 @@ def run(args):
         peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (MFMA_F64_PEAK_TFLOPS, "TFLOP/s", 1e12)}
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "stencil_pmc.json")
-        if os.path.exists(pmc_path):
+        if synthetic:
+            # several coarse levels share the MFMA operator kernel and the PMC figures were taken
+            # on schwinger128: report the stencil and the dense kernel only, without traffic
+            kstats.pop("k_bsr_mfma(level-1 operator)", None)
+        elif os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
             except Exception:
@@ -239,8 +268,9 @@ def run(args):
                       key=lambda r: r["step_ms"], default=None)
         bytes0 = algo["k_stencil<0>"][1]
         out = {
-            "metric": "hutchinson_probe_samples_per_sec_schwinger128" if args.workload == "hutchinson"
-                      else "mlmc_level0_difference_probe_samples_per_sec_schwinger128",
+            "metric": {"hutchinson": "hutchinson_probe_samples_per_sec_schwinger128",
+                       "mlmc": "mlmc_level0_difference_probe_samples_per_sec_schwinger128",
+                       "synthetic": "hutchinson_probe_samples_per_sec_synthetic%d" % L}[args.workload],
             "value": world * ne * args.steps * nb / elapsed,
             "unit": "probe-samples/s",
             "n_gpus": world,
@@ -259,6 +289,9 @@ def run(args):
                             "of %d on separate HIP streams), deflated Hutchinson (k=8, Pperm shift "
                             "512), fp64, tol %.0e" % (ne, nb, ne, nb, args.tol)
                             if args.workload == "hutchinson" else
+                            "synthetic %dx%d random U(1) lattice (sigma 0.204, m -0.05), %d x %d plain "
+                            "Hutchinson probes/GPU/step, GPU-side adaptive MG setup, fp64, tol %.0e"
+                            % (L, L, ne, nb, args.tol) if synthetic else
                             "schwinger128, %d x %d MLMC level-0 difference probes/GPU/step "
                             "(A0^-1 - P0 P1 A2^-1 R1 R0, reference hierarchy 32768/8192/2048/512, "
                             "level skipping), fp64, tol %.0e" % (ne, nb, args.tol),
@@ -279,9 +312,9 @@ def run(args):
             "kernel_rooflines": rooflines,
             "step_breakdown_ms": dict(buckets, kernel_launches=launches),
         }
-        if not args.no_large_stencil:
+        if not args.no_large_stencil and not synthetic:
             out["stencil_roofline_1024"] = large_stencil_point()
-        if world == 1 and not args.no_cpu_baseline and args.workload == "hutchinson":
+        if world == 1 and not args.no_cpu_baseline and args.workload == "hutchinson":  # 128^2 only
             out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes)
         line_out = json.dumps(out)
     if td.is_initialized():

@@ -905,7 +905,8 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
 }
 
 // ---------------------------------------------------------------------------------------------
-// batched right-preconditioned flexible GMRES(m), CGS2 (MG.solve -> fgmres, multigrid.py:347-366)
+// batched right-preconditioned flexible GMRES(m) (MG.solve -> fgmres, multigrid.py:347-366);
+// one classical Gram-Schmidt pass per step (two with option cgs2), true-residual verification
 //  outer == true : restarted, converges every probe to tol (one host read-back per iteration)
 //  outer == false: exactly `maxiter` (= m) steps from a zero guess, no host synchronisation
 // ---------------------------------------------------------------------------------------------

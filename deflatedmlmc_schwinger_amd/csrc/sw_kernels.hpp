@@ -518,7 +518,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
 // Pack / unpack between the reference's host layout ([probe][natural index], probe-major) and
 // the engine layout ([internal row][probe]).  rowmap[natural] = internal row (NULL: identity).
 // ------------------------------------------------------------------------------------------
-// probes: int8 +-1  ->  complex
+// probes: int8 code -> complex.  +-1 are the reference's Rademacher (Z2) entries; the build-only Z4
+// option adds +-2 meaning +-i (BASELINE config 1; not in the reference, utils.py:213-216)
 __global__ __launch_bounds__(SW_BLOCK) void k_pack_i8(const int8_t* __restrict__ src, int nb,
                                                       int n, const int* __restrict__ rowmap,
                                                       cplx* __restrict__ dst, int nbp) {
@@ -536,7 +537,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_pack_i8(const int8_t* __restrict__
     const int i = i0 + ii;
     if (i < n) {
       const size_t row = rowmap ? (size_t)rowmap[i] : (size_t)i;
-      dst[row * nbp + j0 + tx] = cmake((double)tile[tx][ii], 0.0);
+      const int v = tile[tx][ii];
+      dst[row * nbp + j0 + tx] = (v == 2 || v == -2) ? cmake(0.0, (double)(v / 2)) : cmake((double)v, 0.0);
     }
   }
 }

@@ -31,7 +31,7 @@ def _stats(values):
 
 
 def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_index=5,
-                   verbose=False):
+                   verbose=False, probe_type="z2"):
     """The probe loop of stoch_trace.py:137-154 / 386-406 in rounds of batched probes.
 
     evaluate(probes[int8, (k, n)]) -> (ests[k], iters_fine[k], iters_coarse[k]).
@@ -48,7 +48,7 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
     while ests.size < max_nr_ests:
         round_size = min(batch * comm.world, max_nr_ests - ests.size)
         state = np.random.get_state()
-        probes = draw_probes(round_size, n)
+        probes = draw_probes(round_size, n, probe_type)
         lo, hi = comm.my_slice(round_size)
         if hi > lo:
             e, f, c = evaluate(probes[lo:hi])
@@ -76,7 +76,7 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
             used = stop_index - first_new + 1
             if used < round_size:
                 np.random.set_state(state)
-                np.random.randint(2, size=(used, n))
+                np.random.randint(2 if probe_type == "z2" else 4, size=(used, n))
             break
     if stop_index is None:
         stop_index = ests.size - 1
@@ -115,7 +115,7 @@ def _rough_trace(mg_solver, params, n, Vx_rank, tr1):
     """stoch_trace.py:103-115 / 288-302: seed 123456, five deflated Hutchinson probes."""
     np.random.seed(123456)
     t0 = time.time()
-    probes = draw_probes(NR_ROUGH_PROBES, n)
+    probes = draw_probes(NR_ROUGH_PROBES, n, params.get('probe_type', 'z2'))
     e, _, _ = probe_batch(mg_solver, params, "hutchinson", probes, 0)
     rough = np.sum(e[0:NR_ROUGH_PROBES]) / NR_ROUGH_PROBES
     rough += tr1
@@ -156,7 +156,8 @@ def hutchinson(A, params):
         return probe_batch(mg_solver, params, "hutchinson", probes, 0)
 
     loop = run_probe_loop(evaluate, N, rough_trace_tol, params['max_nr_ests'], batch,
-                          verbose=bool(params.get('verbose', False)))
+                          verbose=bool(params.get('verbose', False)),
+                          probe_type=params.get('probe_type', 'z2'))
     print(" done. Time : " + str(time.time() - t0) + " seconds")
 
     function_iters = int(np.sum(loop["iters_fine"]))
@@ -267,7 +268,8 @@ def mlmc(A, params):
         def evaluate(probes, _i=i):
             return probe_batch(mg_solver, params, "mlmc", probes, _i)
 
-        loop = run_probe_loop(evaluate, n_i, level_trace_tol, params['max_nr_ests'], batch)
+        loop = run_probe_loop(evaluate, n_i, level_trace_tol, params['max_nr_ests'], batch,
+                              probe_type=params.get('probe_type', 'z2'))
         res = output_params['results']
         res[i]['function_iters'] += int(np.sum(loop["iters_fine"]))
         res[lc]['function_iters'] += int(np.sum(loop["iters_coarse"]))

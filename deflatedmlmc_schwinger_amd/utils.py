@@ -57,7 +57,7 @@ _COMMON_KEYS = ('max_nr_levels', 'nr_deflat_vctrs', 'defl_eigvs_tol_Hutch', 'acc
 _MLMC_KEYS = ('mlmc_deflat_vctrs', 'defl_eigvs_tol_MLMC', 'diff_lev_op_tol', 'defl_type',
               'coarsest_level_directly', 'mlmc_levels_to_skip')
 # build-only options (all optional; reference presets do not carry them)
-_BUILD_KEYS = ('batch', 'device', 'engines', 'cache_dir', 'report_path', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
+_BUILD_KEYS = ('batch', 'device', 'engines', 'cache_dir', 'report_path', 'probe_type', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
                'solver_testvectors', 'deflation_eigenpairs', 'ref_cycle_post', 'ref_cycle_k',
                'verbose', 'probe_rounds_max')
 
@@ -212,11 +212,26 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
 # ----------------------------------------------------------------------------------------
 # probes
 # ----------------------------------------------------------------------------------------
-def draw_probes(count, n):
-    """`count` Rademacher probes from the GLOBAL NumPy stream, identical to `count` calls of
-    np.random.randint(2, size=n) (utils.py:213-215): int8 array (count, n) of +-1."""
-    bits = np.random.randint(2, size=(count, n))
-    return (2 * bits - 1).astype(np.int8)
+def draw_probes(count, n, kind="z2"):
+    """`count` probes from the GLOBAL NumPy stream as int8 codes, shape (count, n).
+
+    kind "z2" (the reference): identical to `count` calls of np.random.randint(2, size=n)
+    (utils.py:213-215), entries +-1.  kind "z4" (build-only option, BASELINE config 1; NOT in the
+    reference): one draw of np.random.randint(4) per entry, 0,1,2,3 -> 1, i, -1, -i, encoded as
+    +1, +2, -1, -2."""
+    if kind == "z2":
+        bits = np.random.randint(2, size=(count, n))
+        return (2 * bits - 1).astype(np.int8)
+    if kind == "z4":
+        q = np.random.randint(4, size=(count, n))
+        return np.array([1, 2, -1, -2], dtype=np.int8)[q]
+    raise Exception("unknown probe type")
+
+
+def probes_as_complex(probes):
+    """int8 probe codes -> the complex vectors they stand for."""
+    p = np.asarray(probes)
+    return np.where(np.abs(p) == 2, 1j * (p // 2), p).astype(np.complex128)
 
 
 def probe_batch(mg_solver, params, method, probes, level=0):

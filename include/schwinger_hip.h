@@ -114,7 +114,8 @@ int sw_solve(sw_engine* h, int hid, int level0, int nb, const double* B, double*
 #define SW_MODE_HUTCHINSON 0   /* utils.py:210-250 */
 #define SW_MODE_MLMC 1         /* utils.py:252-361 */
 #define SW_MODE_MLMC_SKIP 2    /* utils.py:252-361 with mg_solver.skip_level and i == 0 */
-/* One batch of probes x_k in {-1,+1}^n (int8, nb*n, reference ordering) at `level`:
+/* One batch of probes x_k in {-1,+1}^n (int8, nb*n, reference ordering) at `level`
+ * (build-only extension: entries +-2 encode +-i, i.e. Z4 probes {1,i,-1,-i}):
  *   HUTCHINSON: e_k = x^H A^-1 Pperm^T (x - U U^H x)
  *   MLMC:       e_k = x^H A_f^-1 C x - x^H P A_c^-1 R C x   (SKIP: P0 P1, R1 R0)
  * ests: complex128[nb]; iters: int32[2*nb] = fine-solve and coarse-solve iteration counts. */

@@ -547,3 +547,26 @@ def test_config4_probe_stream_statistics_and_sharding_independence(p128):
         e_shard, _, _ = p128.eng.hutch_batch(MODE_HUTCHINSON, 0, first[r * 64:(r + 1) * 64], 1e-12, 1000)
         ref = e_round[r * 64:(r + 1) * 64]
         assert np.max(np.abs(e_shard - ref) / np.abs(ref)) < 1e-10
+
+
+def test_z4_probes_build_only_option(p16):
+    """BASELINE config 1 asks for Z4 probes; the reference only has Z2 (utils.py:213-216), so Z4
+    is a flagged build-only option: entries {1,i,-1,-i}, e = x^H A^-1 x against the LU oracle,
+    32 probes on 16^2, and the mean against the exact trace within the estimator's error."""
+    n = p16.A.shape[0]
+    np.random.seed(2468)
+    codes = utils.draw_probes(32, n, "z4")
+    assert set(np.unique(codes).tolist()) == {-2, -1, 1, 2}
+    X = utils.probes_as_complex(codes)
+    assert np.allclose(np.abs(X), 1.0)
+    p16.eng.set_deflation(None)
+    try:
+        ests, _, _ = p16.eng.hutch_batch(MODE_HUTCHINSON, 0, codes, 1e-12, 1000)
+    finally:
+        p16.eng.set_deflation(np.asarray(p16.Ux))
+    lu = p16.lu_solver(0)
+    for k in range(32):
+        ref = np.vdot(X[k], lu(X[k]))
+        assert abs(ests[k] - ref) / abs(ref) < 1e-10
+    exact = 265.8581064657958
+    assert abs(ests.mean() - exact) < 4.0 * ests.std() / np.sqrt(32)

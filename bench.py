@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark: Hutchinson probe-samples/s on schwinger128 (BASELINE.json).
 
-One step = one batch of NB (default 256) deflated-Hutchinson probes per GPU, solved as one
-multi-RHS batch in fp64 to a relative residual of 1e-12 (config 2 of BASELINE.json; with
---gpus N the probe stream is sharded in contiguous blocks over N ranks, config 4).  The
-probes of every step are generated and uploaded to HBM before the timed region.  The line
+One step = one batch of NB (default 256) deflated-Hutchinson probes per engine stream per GPU:
+the probes are GENERATED on the GPU inside the timed region (the reference's MT19937 stream,
+bit-exact, k_mt_generate) and solved as one multi-RHS batch in fp64 to a relative residual of
+1e-12 (config 2 of BASELINE.json; with --gpus N the probe stream is sharded in contiguous
+blocks over N ranks, config 4, every rank jumping straight to its stream positions).  The line
 printed by rank 0 also carries
+
+* ``value_probes_resident``: the same steps with the probes already resident in HBM (round 1's
+  headline), and ``value_pcie_inclusive_this_rank``: with host-made probes uploaded per step;
 
 * ``roofline``: achieved algorithmic HBM rate of the batched Wilson stencil kernel, from
   HIP-event timings of that kernel on the engine's stream in an instrumented extra step of
@@ -43,21 +47,48 @@ def parse():
                     help="JSON solver-hierarchy override")
     ap.add_argument("--lattice", type=int, default=1024, help="extent of the synthetic lattice "
                     "(--workload synthetic only)")
-    ap.add_argument("--workload", choices=["hutchinson", "mlmc", "synthetic"], default="hutchinson",
+    ap.add_argument("--workload", choices=["hutchinson", "mlmc", "synthetic", "config2"],
+                    default="hutchinson",
                     help="hutchinson: deflated Hutchinson probes (BASELINE configs 2/4, the "
                          "headline metric); mlmc: level-0 MLMC difference probes with level "
                          "skipping, A0^-1 - P0 P1 A2^-1 R1 R0 (config 3); synthetic: plain Hutchinson "
                          "probes on a synthetic random-gauge --lattice^2 configuration with the "
-                         "GPU-side adaptive setup (config 5; use --nb 64 --streams 1 at 1024)")
+                         "GPU-side adaptive setup (config 5; use --nb 64 --streams 1 at 1024); "
+                         "config2: BASELINE config 2 AS WRITTEN -- plain (k=0) Hutchinson probes, "
+                         "2-level multigrid 32768 -> 8192 built with the reference's aggregation "
+                         "(32-row aggregates, 4 test vectors x 2), dense 8192^2 coarse inverse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
-    ap.add_argument("--cpu-probes", type=int, default=6)
+    ap.add_argument("--cpu-probes", type=int, default=8)
+    ap.add_argument("--cpu-workers", type=int, default=-1,
+                    help="processes of the all-cores CPU baseline line (-1: min(cores, 16); 0: skip)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes
+    (before this process touches the GPU) and leave with their exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s; refusing to report a line for a "
+                         "different rank count\n" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+        sys.exit(2)
     # Libraries (RCCL's version banner at communicator creation, for one) write to the process's
     # stdout; the contract is ONE JSON line there.  Everything written to fd 1 during the run is
     # sent to stderr, the JSON line goes to the real stdout at the end.
@@ -90,8 +121,6 @@ def run(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         td.init_process_group(backend=backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
     line_out = None
     from deflatedmlmc_schwinger_amd import dist as swdist
@@ -149,67 +178,88 @@ def run(args):
     nbp = ((nb + 63) // 64) * 64
     maxiter = 1000
 
-    # ---- inputs: probes of every step, resident in HBM before timing ---------------------
+    # ---- the probe stream: MT19937(123456) as stoch_trace.py:103 seeds it; every engine holds
+    # the window at stream position 0 and jumps to its own block of every round -------------------
     engs = mg.engines
     ne = len(engs)
-    nsteps = args.warmup + args.steps + 1          # +1: instrumented step
-    stream = ProbeStream(123456)
-    for s in range(nsteps):
-        # a round = world * ne batches of nb probes, contiguous blocks per (rank, stream)
-        stream.skip(rank * ne * nb * n)
-        for e in range(ne):
-            engs[e].probes_upload_slot(s, 0, stream.rademacher(nb, n))
-        stream.skip((world - 1 - rank) * ne * nb * n)
+    window0 = ProbeStream(123456).window()
+    for e in range(ne):
+        engs[e].stream_set(window0)
     comm = swdist.TorchComm() if td.is_initialized() else swdist.Comm()
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=ne)
 
-    def run_one(e, s):
-        engs[e].probes_select(s)
+    def first_probe(s, e):
+        # a round = world * ne batches of nb probes, contiguous blocks per (rank, stream)
+        return ((s * world + rank) * ne + e) * nb
+
+    def run_one(e, s, generate=True, slot=0):
+        if generate:
+            engs[e].probes_generate(slot, 0, nb, first_probe(s, e) * n)
+        engs[e].probes_select(slot)
         engs[e].hutch_run(run_mode, 0, args.tol, maxiter)
         return engs[e].hutch_fetch()
 
-    def step(s):
+    def step(s, generate=True, slot=0):
         if ne == 1:
-            res = [run_one(0, s)]
+            res = [run_one(0, s, generate, slot)]
         else:
-            res = list(pool.map(lambda e: run_one(e, s), range(ne)))
+            res = list(pool.map(lambda e: run_one(e, s, generate, slot), range(ne)))
         ests = np.concatenate([r[0] for r in res])
         itf = np.concatenate([r[1] for r in res])
         stats = comm.allreduce_stats(swdist.local_stats(ests))
         return ests, itf, stats
 
+    def timed(fn):
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        comm.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if td.is_initialized():
+            tmax = torch.tensor([dt], dtype=torch.float64,
+                                device="cuda" if backend == "nccl" else "cpu")
+            td.all_reduce(tmax, op=td.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    # ---- the timed region: K steps of generate + solve + reduce ---------------------------------
     for s in range(args.warmup):
         step(s)
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     total = np.zeros(4)
     iters_seen = []
-    for s in range(args.warmup, args.warmup + args.steps):
-        ests, itf, stats = step(s)
-        total += stats
-        iters_seen.append(int(itf.max()))
-    comm.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if td.is_initialized():
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device="cuda" if backend == "nccl" else "cpu")
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
-    # ---- the same steps through the host-buffer boundary (probe upload over PCIe included) ----
-    host_batches = [[ProbeStream(7 + e).rademacher(nb, n) for e in range(ne)]]
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
+    def headline():
+        for s in range(args.warmup, args.warmup + args.steps):
+            ests, itf, stats = step(s)
+            total[:] += stats
+            iters_seen.append(int(itf.max()))
+    elapsed = timed(headline)
+
+    # ---- secondary: the same steps with the probes resident in HBM before the clock starts
+    # (round 1's definition), and with host-made probes uploaded per step (PCIe-inclusive) -------
+    nres = min(args.steps, 8)
+    for i in range(nres):
         for e in range(ne):
-            engs[e].probes_upload_slot(s, 0, host_batches[0][e])
-        step(s)
-    torch.cuda.synchronize()
-    elapsed_pcie = time.perf_counter() - t0
+            engs[e].probes_generate(1 + i, 0, nb, first_probe(args.warmup + i, e) * n)
+    elapsed_resident = timed(lambda: [step(args.warmup + i, False, 1 + i) for i in range(nres)])
+    host_batches = [ProbeStream(7 + e).rademacher(nb, n) for e in range(ne)]
+
+    def pcie():
+        for i in range(nres):
+            for e in range(ne):
+                engs[e].probes_upload_slot(1 + i, 0, host_batches[e])
+            step(args.warmup + i, False, 1 + i)
+    elapsed_pcie = timed(pcie)
+
+    # ---- generation alone (device time of k_mt_jump + k_mt_generate per batch) ------------------
+    def gen_only():
+        for i in range(nres):
+            engs[0].probes_generate(0, 0, nb, first_probe(args.warmup + i, 0) * n)
+        engs[0].sync()
+    gen_ms = 1e3 * timed(gen_only) / nres
 
     # ---- instrumented step: HIP events around every launch, on the engine stream ----------
     eng.set_profiling(True)
@@ -277,13 +327,18 @@ def run(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "value_pcie_inclusive_this_rank": ne * args.steps * nb / elapsed_pcie,
+            "value_probes_resident": world * ne * nres * nb / elapsed_resident,
+            "value_pcie_inclusive_this_rank": ne * nres * nb / elapsed_pcie,
+            "probe_generation_ms_per_batch": gen_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic Rademacher probes (MT19937 seed 123456) on the schwinger128 gauge "
-                    "configuration (link fixture), m0=-0.1320",
+            "data": "synthetic Rademacher probes (the reference's MT19937 stream, seed 123456, "
+                    "generated on the GPU inside the timed region) on the schwinger128 gauge "
+                    "configuration (link fixture), m0=-0.1320" if not synthetic else
+                    "synthetic Rademacher probes (MT19937 seed 123456, generated on the GPU inside "
+                    "the timed region) on a synthetic random U(1) gauge configuration (seed 2024)",
             "config": {
                 "workload": "schwinger128, %d x %d probes/GPU/step (%d concurrent multi-RHS batches "
                             "of %d on separate HIP streams), deflated Hutchinson (k=8, Pperm shift "

@@ -156,6 +156,17 @@ struct sw_engine {
     int level = -1, nb = 0;
   };
   std::vector<ProbeSlot> slots;
+  // device probe stream (k_mt_jump / k_mt_generate): window = 624 raw MT19937 words at mt_pos
+  bool mt_set = false;
+  uint32_t* mt_win0 = nullptr;      // window at stream position 0 (as handed to sw_probes_stream_set)
+  uint32_t* mt_win = nullptr;       // [2][624] double buffer, mt_win + 624*mt_cur is current
+  int mt_cur = 0;
+  uint64_t mt_pos = 0;              // stream position (draws) of the current window
+  uint32_t* mt_poly = nullptr;      // [624] x^mt_dist mod phi
+  uint64_t mt_dist = 0;
+  uint32_t* mt_family = nullptr;    // [mt_fam_count][624]: x^(s*mt_fam_seg), s = 1..count
+  uint64_t mt_fam_seg = 0;
+  int mt_fam_count = 0;
   cplx *pb_x0 = nullptr, *pb_rhs = nullptr, *pb_z = nullptr, *pb_xc = nullptr, *pb_xc2 = nullptr,
        *pb_y = nullptr, *pb_w = nullptr, *pb_w2 = nullptr, *pb_xd = nullptr;
   int pb_ws_nbp = 0;
@@ -1658,6 +1669,116 @@ int sw_probes_select(sw_engine* h, int slot) {
 int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes) {
   SWCHK(sw_probes_upload_slot(h, 0, level, nb, probes));
   return sw_probes_select(h, 0);
+}
+
+// ---- device-side probe generation --------------------------------------------------------
+int sw_probes_stream_set(sw_engine* h, const uint32_t* window) {
+  if (!h) return 1;
+  if (!window) return sw_fail(h, "null MT19937 window");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->mt_win0) SWCHK(dev_realloc(h, &h->mt_win0, (size_t)SW_MT_N));
+  if (!h->mt_win) SWCHK(dev_realloc(h, &h->mt_win, (size_t)2 * SW_MT_N));
+  if (!h->mt_poly) SWCHK(dev_realloc(h, &h->mt_poly, (size_t)SW_MT_N));
+  HIPCHK(hipMemcpyAsync(h->mt_win0, window, SW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice,
+                        h->stream));
+  HIPCHK(hipMemcpyAsync(h->mt_win, window, SW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice,
+                        h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->mt_cur = 0;
+  h->mt_pos = 0;
+  h->mt_dist = 0;
+  h->mt_set = true;
+  return 0;
+}
+
+// probes per generator segment: segments of ~64K draws (105 state blocks), whole probes
+static inline int mt_probes_per_segment(int n) { return std::max(1, 65536 / n); }
+
+int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint64_t pos) {
+  SWCHK(check_hier(h, 0, level, true));
+  if (!h->mt_set) return sw_fail(h, "no probe stream set (sw_probes_stream_set)");
+  if (nb <= 0) return sw_fail(h, "bad arguments");
+  if (kind != SW_PROBES_Z2 && kind != SW_PROBES_Z4) return sw_fail(h, "unknown probe kind %d", kind);
+  if (slot < 0 || slot >= 4096) return sw_fail(h, "probe slot %d out of range", slot);
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[0].lv[level];
+  const int n = lv.n;
+  if (n % 4) return sw_fail(h, "device probe generation needs n %% 4 == 0 (n = %d)", n);
+  const uint64_t total = (uint64_t)nb * (uint64_t)n;
+  // 1. move the resident window to `pos`
+  if (pos < h->mt_pos) {
+    HIPCHK(hipMemcpyAsync(h->mt_win + (size_t)SW_MT_N * h->mt_cur, h->mt_win0,
+                          SW_MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+    h->mt_pos = 0;
+  }
+  if (pos > h->mt_pos) {
+    const uint64_t dist = pos - h->mt_pos;
+    if (dist != h->mt_dist) {
+      uint32_t poly[SW_MT_N];
+      if (sw_mt_jump_poly(dist, poly) != 0) return sw_fail(h, "jump polynomial construction failed");
+      // the previous polynomial may still be in use by a queued k_mt_jump: stream order protects it
+      HIPCHK(hipMemcpyAsync(h->mt_poly, poly, sizeof poly, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));   // `poly` is a stack buffer
+      h->mt_dist = dist;
+    }
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_mt_jump, dim3(1), dim3(SW_MT_BLOCK), 0, h->stream,
+                       (const uint32_t*)(h->mt_win + (size_t)SW_MT_N * h->mt_cur),
+                       (const uint32_t*)h->mt_poly, h->mt_win + (size_t)SW_MT_N * (1 - h->mt_cur));
+    KLAUNCH_CHECK();
+    h->mt_cur = 1 - h->mt_cur;
+    h->mt_pos = pos;
+  }
+  // 2. the polynomial family of the segment starts
+  const int pps = mt_probes_per_segment(n);
+  const uint64_t segdraws = (uint64_t)pps * (uint64_t)n;
+  const int S = (nb + pps - 1) / pps;
+  if (S > 1 && (h->mt_fam_seg != segdraws || h->mt_fam_count < S - 1)) {
+    std::vector<uint32_t> fam((size_t)(S - 1) * SW_MT_N);
+    for (int s = 1; s < S; ++s)
+      if (sw_mt_jump_poly((uint64_t)s * segdraws, &fam[(size_t)(s - 1) * SW_MT_N]) != 0)
+        return sw_fail(h, "jump polynomial construction failed");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    SWCHK(upload(h, &h->mt_family, fam.data(), fam.size()));
+    h->mt_fam_seg = segdraws;
+    h->mt_fam_count = S - 1;
+  }
+  // 3. generate into the slot
+  if ((int)h->slots.size() <= slot) h->slots.resize(slot + 1);
+  sw_engine::ProbeSlot& sl = h->slots[slot];
+  if (sl.bytes < total) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    SWCHK(dev_free(h, sl.p));
+    sl.p = nullptr;
+    void* q;
+    SWCHK(dev_alloc(h, &q, total));
+    sl.p = (int8_t*)q;
+    sl.bytes = total;
+  }
+  {
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_mt_generate, dim3(S), dim3(SW_MT_BLOCK), 0, h->stream,
+                       (const uint32_t*)(h->mt_win + (size_t)SW_MT_N * h->mt_cur),
+                       (const uint32_t*)h->mt_family, (unsigned long long)segdraws,
+                       (unsigned long long)total, kind, sl.p);
+    KLAUNCH_CHECK();
+  }
+  sl.level = level;
+  sl.nb = nb;
+  return 0;
+}
+
+int sw_probes_fetch(sw_engine* h, int slot, int8_t* out) {
+  if (!h) return 1;
+  if (!out) return sw_fail(h, "null output");
+  if (slot < 0 || slot >= (int)h->slots.size() || !h->slots[slot].p)
+    return sw_fail(h, "probe slot %d is empty", slot);
+  HIPCHK(hipSetDevice(h->device));
+  SWCHK(stream_sync(h));
+  const sw_engine::ProbeSlot& sl = h->slots[slot];
+  const size_t bytes = (size_t)sl.nb * h->hier[0].lv[sl.level].n;
+  HIPCHK(hipMemcpy(out, sl.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 static int dot_into(sw_engine* h, const cplx* A, const cplx* Bv, int n, int nbp, cplx* out) {

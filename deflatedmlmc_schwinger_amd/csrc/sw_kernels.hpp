@@ -586,6 +586,169 @@ __global__ __launch_bounds__(SW_BLOCK) void k_unpack_c(const cplx* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Device-side probe generation: the reference's MT19937 stream (np.random.randint(2, size=n),
+// utils.py:213-216,255-258), bit-exact, started anywhere in the stream.
+//   window = the 624 raw (untempered) words w[p .. p+623] at stream position p (draw index).
+//   jump   : window at p + J:  W'[k] = XOR_{i : g_i = 1} w[p + i + k],  g = x^J mod phi (host,
+//            sw_mt19937.cpp); the 20560-word table w lives in LDS (82 KB), thread k accumulates
+//            its output word with wave-uniform polynomial bits from the scalar path.
+//   generate: the word recurrence w[t+624] = w[t+397] ^ twist(w[t], w[t+1]) is parallel over 227
+//            consecutive t, i.e. one 624-word block = three barrier-separated phases.
+// One workgroup = one segment of the batch: it jumps from the batch's base window to its own
+// start (polynomial s of the family x^(s*segdraws)), then walks its segment block by block,
+// tempering each word and storing the probe entries as int8 codes in the layout an uploaded
+// probe batch has ([probe][natural index]; +-1 = Z2, +-1/+-2 = Z4), four entries per store.
+// ------------------------------------------------------------------------------------------
+#define SW_MT_N 624
+#define SW_MT_M 397
+#define SW_MT_DEG 19937
+#define SW_MT_TABLE (SW_MT_DEG + SW_MT_N)   // w[i + k], i < DEG, k < 624
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+#define SW_MT_BLOCK 1024   // 16 waves: the convolution is LDS-latency bound, its i-range is split 4 ways
+
+// w[0..623] valid on entry; fills w[624 .. SW_MT_TABLE-1].  All threads of the block must call.
+__device__ __forceinline__ void mt_extend_table(uint32_t* w) {
+  const int tid = threadIdx.x;
+  for (int base = 0; base + SW_MT_N < SW_MT_TABLE; base += 227) {
+    const int t = base + tid;
+    if (tid < 227 && t + SW_MT_N < SW_MT_TABLE) w[t + SW_MT_N] = w[t + SW_MT_M] ^ mt_twist(w[t], w[t + 1]);
+    __syncthreads();
+  }
+}
+
+// Jumped window into dst[0..623] (LDS or global).  Thread (q, t) = (tid >> 8, tid & 255) takes the
+// polynomial words [156 q, 156 q + 156) and the output words k = t, t + 256, t + 512; the four
+// partial sums meet in `red` ([4][3][256] words of LDS).  All 1024 threads must call.
+__device__ __forceinline__ void mt_convolve(const uint32_t* w, const uint32_t* __restrict__ poly,
+                                            uint32_t* red, uint32_t* dst) {
+  const int tid = threadIdx.x;
+  const int q = tid >> 8, t = tid & 255;
+  uint32_t a0 = 0u, a1 = 0u, a2 = 0u;
+  const bool third = (t + 512) < SW_MT_N;
+  const int w0 = __builtin_amdgcn_readfirstlane(q * (SW_MT_N / 4));
+  for (int wi = w0; wi < w0 + SW_MT_N / 4; ++wi) {
+    uint32_t bits = __builtin_amdgcn_readfirstlane(poly[wi]);
+    const uint32_t* wb = w + wi * 32 + t;
+    while (bits) {
+      const int b = __builtin_ctz(bits);
+      bits &= bits - 1;
+      a0 ^= wb[b];
+      a1 ^= wb[b + 256];
+      if (third) a2 ^= wb[b + 512];
+    }
+  }
+  red[(q * 3 + 0) * 256 + t] = a0;
+  red[(q * 3 + 1) * 256 + t] = a1;
+  red[(q * 3 + 2) * 256 + t] = a2;
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int k = t + 256 * r;
+      if (k < SW_MT_N)
+        dst[k] = red[(0 * 3 + r) * 256 + t] ^ red[(1 * 3 + r) * 256 + t] ^
+                 red[(2 * 3 + r) * 256 + t] ^ red[(3 * 3 + r) * 256 + t];
+    }
+  }
+  __syncthreads();
+}
+
+// window_out = window_in advanced by the jump polynomial `poly` (one workgroup)
+__global__ __launch_bounds__(SW_MT_BLOCK) void k_mt_jump(const uint32_t* __restrict__ win_in,
+                                                         const uint32_t* __restrict__ poly,
+                                                         uint32_t* __restrict__ win_out) {
+  __shared__ uint32_t w[SW_MT_TABLE + 8];
+  __shared__ uint32_t red[4 * 3 * 256];
+  const int tid = threadIdx.x;
+  if (tid < SW_MT_N) w[tid] = win_in[tid];
+  __syncthreads();
+  mt_extend_table(w);
+  mt_convolve(w, poly, red, win_out);
+}
+
+// kind 1: Z2 (entry = 2 (y & 1) - 1);  kind 2: Z4 (y & 3 -> 1, i, -1, -i  ==  codes 1, 2, -1, -2)
+__device__ __forceinline__ int mt_code(uint32_t y, int kind) {
+  if (kind == 1) return 2 * (int)(y & 1u) - 1;
+  const int q = (int)(y & 3u);
+  return (q == 0) ? 1 : (q == 1) ? 2 : (q == 2) ? -1 : -2;
+}
+
+// grid = number of segments; segment s covers draws [s*segdraws, min(total, (s+1)*segdraws)) of the
+// batch that starts at `win` ; polys[(s-1)*624 ..] = x^(s*segdraws) mod phi.  segdraws % 4 == 0.
+__global__ __launch_bounds__(SW_MT_BLOCK) void k_mt_generate(const uint32_t* __restrict__ win,
+                                                             const uint32_t* __restrict__ polys,
+                                                             unsigned long long segdraws,
+                                                             unsigned long long total, int kind,
+                                                             int8_t* __restrict__ out) {
+  __shared__ uint32_t w[SW_MT_TABLE + 8];
+  __shared__ uint32_t red[4 * 3 * 256];
+  __shared__ __attribute__((aligned(16))) uint32_t st[SW_MT_N];
+  const int tid = threadIdx.x;
+  const int s = blockIdx.x;
+  if (tid < SW_MT_N) w[tid] = win[tid];
+  __syncthreads();
+  if (s > 0) {
+    mt_extend_table(w);
+    mt_convolve(w, polys + (size_t)(s - 1) * SW_MT_N, red, st);
+  } else {
+    if (tid < SW_MT_N) st[tid] = w[tid];
+    __syncthreads();
+  }
+  // the walk along the segment needs 227 threads: waves 4..15 end here (whole waves; s_barrier
+  // waits only on the waves of the workgroup that are still running, CDNA ISA "S_BARRIER")
+  if (tid >= 256) return;
+  const unsigned long long d0 = (unsigned long long)s * segdraws;
+  const unsigned long long d1 = (d0 + segdraws < total) ? d0 + segdraws : total;
+  for (unsigned long long d = d0; d < d1; d += SW_MT_N) {
+    // emit the block: thread q < 156 takes words 4q .. 4q+3
+    if (tid < SW_MT_N / 4) {
+      const unsigned long long e = d + 4ull * tid;
+      if (e < d1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&st[4 * tid]);
+        const int c0 = mt_code(mt_temper(v.x), kind), c1 = mt_code(mt_temper(v.y), kind);
+        const int c2 = mt_code(mt_temper(v.z), kind), c3 = mt_code(mt_temper(v.w), kind);
+        if (e + 4 <= d1) {
+          const uint32_t pk = (uint32_t)(c0 & 0xff) | ((uint32_t)(c1 & 0xff) << 8) |
+                              ((uint32_t)(c2 & 0xff) << 16) | ((uint32_t)(c3 & 0xff) << 24);
+          *reinterpret_cast<uint32_t*>(out + e) = pk;
+        } else {
+          out[e] = (int8_t)c0;
+          if (e + 1 < d1) out[e + 1] = (int8_t)c1;
+          if (e + 2 < d1) out[e + 2] = (int8_t)c2;
+        }
+      }
+    }
+    if (d + SW_MT_N >= d1) break;
+    // next block in place: three phases of <= 227 independent words
+    uint32_t a = 0, b = 0, c = 0;
+    if (tid < 227) { a = st[tid]; b = st[tid + 1]; c = st[tid + SW_MT_M]; }
+    __syncthreads();
+    if (tid < 227) st[tid] = c ^ mt_twist(a, b);
+    __syncthreads();
+    if (tid < 227) { a = st[227 + tid]; b = st[228 + tid]; c = st[tid]; }
+    __syncthreads();
+    if (tid < 227) st[227 + tid] = c ^ mt_twist(a, b);
+    __syncthreads();
+    if (tid < 170) { a = st[454 + tid]; b = st[(tid == 169) ? 0 : 455 + tid]; c = st[227 + tid]; }
+    __syncthreads();
+    if (tid < 170) st[454 + tid] = c ^ mt_twist(a, b);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Batched BLAS-1.  All of them: lane == probe, grid.y == 64-probe chunk.
 // ------------------------------------------------------------------------------------------
 #define SW_MAXK 34   // restart cap 32, + w itself + 1

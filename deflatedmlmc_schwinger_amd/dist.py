@@ -22,6 +22,13 @@ class Comm:
     def allgather(self, arrays, count):
         return arrays
 
+    def allgather_probe_results(self, e, f, c, count):
+        return (np.asarray(e, dtype=np.complex128), np.asarray(f, dtype=np.int64),
+                np.asarray(c, dtype=np.int64))
+
+    def broadcast_arrays(self, arrays, src=0):
+        return arrays
+
     def allreduce_stats(self, stats):
         return np.asarray(stats, dtype=np.float64)
 
@@ -75,6 +82,42 @@ class TorchComm(Comm):
                 b = bufs[r].cpu().numpy()[:sizes[r]]
                 parts.append(b[:, 0] + 1j * b[:, 1] if is_c else b[:, 0].astype(a.dtype))
             out.append(np.concatenate(parts))
+        return out
+
+    def allgather_probe_results(self, e, f, c, count):
+        """ONE collective per round: this rank's per-probe (estimate, fine iterations, coarse
+        iterations) packed as (width, 4) float64 rows, gathered in probe order."""
+        torch, td = self._torch, self._td
+        sizes = [((r + 1) * count) // self.world - (r * count) // self.world
+                 for r in range(self.world)]
+        width = max(sizes)
+        e = np.asarray(e, dtype=np.complex128)
+        loc = np.zeros((width, 4), dtype=np.float64)
+        loc[:e.size, 0] = e.real
+        loc[:e.size, 1] = e.imag
+        loc[:e.size, 2] = np.asarray(f, dtype=np.float64)      # iteration counts << 2^53: exact
+        loc[:e.size, 3] = np.asarray(c, dtype=np.float64)
+        t = torch.from_numpy(loc.reshape(-1)).to(self.device)
+        out = torch.empty(self.world * width * 4, dtype=torch.float64, device=self.device)
+        td.all_gather_into_tensor(out, t)
+        full = out.cpu().numpy().reshape(self.world, width, 4)
+        parts = [full[r, :sizes[r]] for r in range(self.world)]
+        g = np.concatenate(parts, axis=0)
+        return (g[:, 0] + 1j * g[:, 1], g[:, 2].astype(np.int64), g[:, 3].astype(np.int64))
+
+    def broadcast_arrays(self, arrays, src=0):
+        """Rank `src`'s NumPy arrays on every rank (setup operands: test vectors, eigenpairs),
+        byte-identical.  Other ranks pass arrays of the same shape/dtype or None placeholders
+        described by (shape, dtype) tuples."""
+        torch, td = self._torch, self._td
+        out = []
+        for a in arrays:
+            if isinstance(a, tuple):
+                a = np.empty(a[0], dtype=a[1])
+            a = np.ascontiguousarray(a)
+            t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self.device)
+            td.broadcast(t, src=src)
+            out.append(t.cpu().numpy().view(a.dtype).reshape(a.shape))
         return out
 
     def allreduce_stats(self, stats):

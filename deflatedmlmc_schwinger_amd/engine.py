@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libschwinger_hip.so")
 MODE_HUTCHINSON = 0
 MODE_MLMC = 1
 MODE_MLMC_SKIP = 2
+PROBES_Z2 = 1
+PROBES_Z4 = 2
+PROBE_KINDS = {"z2": PROBES_Z2, "z4": PROBES_Z4}
 
 TIMER_NAMES = ("mvm", "defl", "P", "R", "axpy", "dots", "coarsest", "other")
 
@@ -93,6 +96,16 @@ def load_library():
     sig("sw_mt_skip", None, vp, C.c_uint64)
     sig("sw_mt_raw", None, vp, C.c_uint64, vp)
     sig("sw_mt_rademacher", None, vp, C.c_uint64, vp)
+    sig("sw_mt_z4", None, vp, C.c_uint64, vp)
+    sig("sw_mt_from_state", vp, vp, i32)
+    sig("sw_mt_get_state", None, vp, vp, P(i32))
+    sig("sw_mt_window", None, vp, vp)
+    sig("sw_mt_jump", i32, vp, C.c_uint64)
+    sig("sw_mt_jump_poly", i32, C.c_uint64, vp)
+    sig("sw_mt_window_jump", i32, vp, C.c_uint64, vp)
+    sig("sw_probes_stream_set", i32, vp, vp)
+    sig("sw_probes_generate", i32, vp, i32, i32, i32, i32, C.c_uint64)
+    sig("sw_probes_fetch", i32, vp, i32, vp)
     _lib = lib
     return lib
 
@@ -106,6 +119,9 @@ EXPORTED_SYMBOLS = (
     "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
     "sw_bench_dirac", "sw_set_profiling", "sw_timers", "sw_timers_reset", "sw_launch_count",
     "sw_mt_create", "sw_mt_destroy", "sw_mt_skip", "sw_mt_raw", "sw_mt_rademacher",
+    "sw_mt_z4", "sw_mt_from_state", "sw_mt_get_state", "sw_mt_window", "sw_mt_jump",
+    "sw_mt_jump_poly", "sw_mt_window_jump",
+    "sw_probes_stream_set", "sw_probes_generate", "sw_probes_fetch",
 )
 
 
@@ -336,6 +352,33 @@ class Engine:
         self._chk(self._lib.sw_probes_select(self._h, slot), "sw_probes_select")
         self._nb_uploaded = self._slot_nb[slot]
 
+    def stream_set(self, window):
+        """Hand the engine a window of the MT19937 probe stream (ProbeStream.window()); it
+        becomes stream position 0 of probes_generate()."""
+        w = np.ascontiguousarray(window, dtype=np.uint32)
+        if w.size != 624:
+            raise EngineError("an MT19937 window has 624 words")
+        self._chk(self._lib.sw_probes_stream_set(self._h, _ptr(w)), "sw_probes_stream_set")
+
+    def probes_generate(self, slot, level, nb, pos, kind="z2"):
+        """Fill `slot` on the device with the nb probes that start at draw `pos` of the stream."""
+        self._chk(self._lib.sw_probes_generate(self._h, int(slot), int(level), int(nb),
+                                               PROBE_KINDS[kind], int(pos)), "sw_probes_generate")
+        self._slot_nb = getattr(self, "_slot_nb", {})
+        self._slot_nb[slot] = int(nb)
+        self._slot_n = getattr(self, "_slot_n", {})
+        self._slot_n[slot] = self.level_sizes[0][level]
+
+    def probes_fetch(self, slot):
+        """int8 codes held in `slot`, shape (nb, n) (tests; the estimators never need them)."""
+        nb = self._slot_nb[slot]
+        n = getattr(self, "_slot_n", {}).get(slot)
+        if n is None:
+            raise EngineError("slot %d was not generated on the device" % slot)
+        out = np.empty((nb, n), dtype=np.int8)
+        self._chk(self._lib.sw_probes_fetch(self._h, int(slot), _ptr(out)), "sw_probes_fetch")
+        return out
+
     def kernel_stats(self, which):
         ms = C.c_double(0.0)
         cnt = C.c_int64(0)
@@ -382,17 +425,52 @@ class Engine:
 
 
 class ProbeStream:
-    """The reference's Rademacher stream (utils.py:213-216) without NumPy's global state:
-    MT19937 seeded as ``np.random.seed(seed)``; host-only, needs no GPU."""
+    """The reference's probe stream (utils.py:213-216) without NumPy's global state: MT19937
+    seeded as ``np.random.seed(seed)``; host-only, needs no GPU.  ``jump`` moves any distance in
+    O(1) state refills (GF(2) jump polynomial), ``skip`` walks there (the checker)."""
 
-    def __init__(self, seed):
+    def __init__(self, seed=None, _handle=None):
         self._lib = load_library()
-        self._g = self._lib.sw_mt_create(int(seed) & 0xFFFFFFFF)
+        if _handle is not None:
+            self._g = _handle
+        else:
+            self._g = self._lib.sw_mt_create(int(seed) & 0xFFFFFFFF)
         if not self._g:
             raise EngineError("sw_mt_create failed")
 
+    @classmethod
+    def from_numpy_state(cls, state=None):
+        """Continue the legacy global NumPy stream (np.random.get_state() by default)."""
+        lib = load_library()
+        st = np.random.get_state() if state is None else state
+        if st[0] != 'MT19937':
+            raise EngineError("not an MT19937 state")
+        key = np.ascontiguousarray(st[1], dtype=np.uint32)
+        g = lib.sw_mt_from_state(_ptr(key), int(st[2]))
+        return cls(_handle=g)
+
+    def numpy_state(self):
+        """State tuple for np.random.set_state (same stream from here on)."""
+        key = np.empty(624, dtype=np.uint32)
+        pos = C.c_int(0)
+        self._lib.sw_mt_get_state(self._g, _ptr(key), C.byref(pos))
+        return ('MT19937', key, int(pos.value), 0, 0.0)
+
+    def copy(self):
+        return ProbeStream.from_numpy_state(self.numpy_state())
+
     def skip(self, ndraws):
         self._lib.sw_mt_skip(self._g, int(ndraws))
+
+    def jump(self, ndraws):
+        if self._lib.sw_mt_jump(self._g, int(ndraws)) != 0:
+            raise EngineError("sw_mt_jump failed")
+
+    def window(self):
+        """The 624 raw words at the current position (Engine.stream_set)."""
+        out = np.empty(624, dtype=np.uint32)
+        self._lib.sw_mt_window(self._g, _ptr(out))
+        return out
 
     def raw(self, n):
         out = np.empty(int(n), dtype=np.uint32)
@@ -403,6 +481,14 @@ class ProbeStream:
         out = np.empty((int(count), int(n)), dtype=np.int8)
         self._lib.sw_mt_rademacher(self._g, int(count) * int(n), _ptr(out))
         return out
+
+    def z4(self, count, n):
+        out = np.empty((int(count), int(n)), dtype=np.int8)
+        self._lib.sw_mt_z4(self._g, int(count) * int(n), _ptr(out))
+        return out
+
+    def probes(self, count, n, kind="z2"):
+        return self.rademacher(count, n) if kind == "z2" else self.z4(count, n)
 
     def __del__(self):  # pragma: no cover
         try:

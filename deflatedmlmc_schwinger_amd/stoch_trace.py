@@ -15,8 +15,10 @@ from scipy.sparse import csr_matrix
 from scipy.sparse.linalg import LinearOperator
 
 from . import dist as _dist
+from .engine import ProbeStream
 from .multigrid import MG
-from .utils import (deflation_pre_computations, draw_probes, flopsV_manual, probe_batch)
+from .utils import (_engines, deflation_pre_computations, draw_probes, flopsV_manual, probe_batch,
+                    probe_batch_generated)
 
 DEFAULT_BATCH = 256
 NR_ROUGH_PROBES = 5
@@ -30,15 +32,63 @@ def _stats(values):
     return avg, dev
 
 
+class HostProbes:
+    """Probe source for evaluators that take the probes themselves (int8, (k, n)): this rank's
+    slice of a round is produced on the host by the C MT19937 stream at its stream positions
+    (jump polynomial, no walk over the other ranks' draws)."""
+
+    def __init__(self, evaluate, n, kind="z2"):
+        self.evaluate = evaluate
+        self.n = n
+        self.kind = kind
+        self._entry = None
+
+    def begin(self, entry_stream):
+        self._entry = entry_stream
+
+    def __call__(self, first_probe, count):
+        g = self._entry.copy()
+        g.jump(first_probe * self.n)
+        return self.evaluate(g.probes(count, self.n, self.kind))
+
+
+class DeviceProbes:
+    """Probe source of the GPU estimators: the engines generate their probes in HBM at the
+    probes' stream positions (k_mt_generate) and evaluate them; nothing of size n touches the host."""
+
+    def __init__(self, mg_solver, params, method, level, kind="z2"):
+        self.mg_solver = mg_solver
+        self.params = params
+        self.method = method
+        self.level = level
+        self.kind = kind
+
+    def begin(self, entry_stream):
+        window = entry_stream.window()
+        for eng in _engines(self.mg_solver):
+            eng.stream_set(window)
+
+    def __call__(self, first_probe, count):
+        return probe_batch_generated(self.mg_solver, self.params, self.method, self.level,
+                                     first_probe, count, self.kind)
+
+
 def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_index=5,
                    verbose=False, probe_type="z2"):
     """The probe loop of stoch_trace.py:137-154 / 386-406 in rounds of batched probes.
 
-    evaluate(probes[int8, (k, n)]) -> (ests[k], iters_fine[k], iters_coarse[k]).
+    `evaluate` is a probe source -- called as source(first_probe, count) for the probes
+    [first_probe, first_probe + count) of the loop, counted from the position of the global NumPy
+    stream on entry (:class:`DeviceProbes`, :class:`HostProbes`) -- or a plain callable
+    evaluate(probes[int8, (k, n)]) -> (ests[k], iters_fine[k], iters_coarse[k]), which is wrapped
+    in :class:`HostProbes`.  Every rank evaluates only its contiguous slice of a round.
     Returns dict(index, avg, dev, ests, iters_fine, iters_coarse, rounds) where `index` is the
     loop index at which the reference would have left the loop.  On return the global NumPy
     stream sits exactly where the one-by-one loop would have left it."""
     comm = comm or _dist.default_comm()
+    source = evaluate if hasattr(evaluate, "begin") else HostProbes(evaluate, n, probe_type)
+    entry = ProbeStream.from_numpy_state()
+    source.begin(entry)
     ests = np.zeros(0, dtype=np.complex128)
     it_f = np.zeros(0, dtype=np.int64)
     it_c = np.zeros(0, dtype=np.int64)
@@ -47,17 +97,13 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
     avg = dev = 0.0
     while ests.size < max_nr_ests:
         round_size = min(batch * comm.world, max_nr_ests - ests.size)
-        state = np.random.get_state()
-        probes = draw_probes(round_size, n, probe_type)
+        first_new = ests.size
         lo, hi = comm.my_slice(round_size)
         if hi > lo:
-            e, f, c = evaluate(probes[lo:hi])
+            e, f, c = source(first_new + lo, hi - lo)
         else:
             e, f, c = np.zeros(0, complex), np.zeros(0, np.int64), np.zeros(0, np.int64)
-        e, f, c = comm.allgather([np.asarray(e, dtype=np.complex128),
-                                  np.asarray(f, dtype=np.int64),
-                                  np.asarray(c, dtype=np.int64)], round_size)
-        first_new = ests.size
+        e, f, c = comm.allgather_probe_results(e, f, c, round_size)
         ests = np.concatenate([ests, e])
         it_f = np.concatenate([it_f, f])
         it_c = np.concatenate([it_c, c])
@@ -73,15 +119,14 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
                 stop_index = i
                 break
         if stop_index is not None:
-            used = stop_index - first_new + 1
-            if used < round_size:
-                np.random.set_state(state)
-                np.random.randint(2 if probe_type == "z2" else 4, size=(used, n))
             break
     if stop_index is None:
         stop_index = ests.size - 1
         avg, dev = _stats(ests)
     k = stop_index + 1
+    # leave the global stream where the one-by-one loop leaves it: k probes of n draws each
+    entry.jump(k * n)
+    np.random.set_state(entry.numpy_state())
     return {"index": stop_index, "avg": avg, "dev": dev, "ests": ests[:k],
             "iters_fine": it_f[:k], "iters_coarse": it_c[:k], "rounds": rounds}
 
@@ -152,10 +197,8 @@ def hutchinson(A, params):
     t0 = time.time()
     mg_solver.coarsest_lev_iters[0] = 0
 
-    def evaluate(probes):
-        return probe_batch(mg_solver, params, "hutchinson", probes, 0)
-
-    loop = run_probe_loop(evaluate, N, rough_trace_tol, params['max_nr_ests'], batch,
+    source = DeviceProbes(mg_solver, params, "hutchinson", 0, params.get('probe_type', 'z2'))
+    loop = run_probe_loop(source, N, rough_trace_tol, params['max_nr_ests'], batch,
                           verbose=bool(params.get('verbose', False)),
                           probe_type=params.get('probe_type', 'z2'))
     print(" done. Time : " + str(time.time() - t0) + " seconds")
@@ -265,10 +308,8 @@ def mlmc(A, params):
         lc = i + 2 if (skip_level and i == 0) else i + 1
         print("Computing for level " + str(i) + " ...", end='', flush=True)
 
-        def evaluate(probes, _i=i):
-            return probe_batch(mg_solver, params, "mlmc", probes, _i)
-
-        loop = run_probe_loop(evaluate, n_i, level_trace_tol, params['max_nr_ests'], batch,
+        source = DeviceProbes(mg_solver, params, "mlmc", i, params.get('probe_type', 'z2'))
+        loop = run_probe_loop(source, n_i, level_trace_tol, params['max_nr_ests'], batch,
                               probe_type=params.get('probe_type', 'z2'))
         res = output_params['results']
         res[i]['function_iters'] += int(np.sum(loop["iters_fine"]))

@@ -267,6 +267,44 @@ def probe_batch(mg_solver, params, method, probes, level=0):
     return tuple(np.concatenate([r[k] for r in res]) for k in range(3))
 
 
+def _probe_mode(mg_solver, method, level):
+    if method == "hutchinson":
+        return MODE_HUTCHINSON
+    if method == "mlmc":
+        return MODE_MLMC_SKIP if (mg_solver.skip_level and level == 0) else MODE_MLMC
+    raise Exception("unknown method")
+
+
+def probe_batch_generated(mg_solver, params, method, level, first_probe, count, kind="z2"):
+    """Like probe_batch, for the probes [first_probe, first_probe + count) of the stream the
+    engines were handed with Engine.stream_set: each engine GENERATES its contiguous share in
+    HBM (k_mt_generate, bit-exact with np.random.randint, utils.py:213-216,255-258) and
+    evaluates it; only the 16-byte estimates come back."""
+    engs = _engines(mg_solver)
+    if not engs:
+        raise EngineError("no GPU engine attached (run MG.setup first)")
+    tol = params['function_params']['tol']
+    n = mg_solver.ml.levels[level].A.shape[0]
+    maxiter = n if n < 1000 else 1000
+    mode = _probe_mode(mg_solver, method, level)
+
+    def run(eng, lo, cnt):
+        eng.probes_generate(0, level, cnt, (first_probe + lo) * n, kind)
+        eng.probes_select(0)
+        eng.hutch_run(mode, level, tol, maxiter)
+        return eng.hutch_fetch()
+
+    if len(engs) == 1 or count < 2 * 64:
+        return run(engs[0], 0, count)
+    from concurrent.futures import ThreadPoolExecutor
+    bounds = [(k * count) // len(engs) for k in range(len(engs) + 1)]
+    with ThreadPoolExecutor(max_workers=len(engs)) as pool:
+        futs = [pool.submit(run, eng, bounds[k], bounds[k + 1] - bounds[k])
+                for k, eng in enumerate(engs) if bounds[k + 1] > bounds[k]]
+        res = [f.result() for f in futs]
+    return tuple(np.concatenate([r[k] for r in res]) for k in range(3))
+
+
 def one_defl_Hutch_step(Af, Ac, mg_solver, params, method, nr_deflat_vctrs, Vx, Ux, i=0,
                         output_params=None, P=None, R=None, Pn=None, Rn=None):
     """utils.py:207-361, one probe.  The probe comes from the global NumPy stream exactly as in

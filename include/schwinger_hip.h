@@ -127,6 +127,19 @@ int sw_probes_upload(sw_engine* h, int level, int nb, const int8_t* probes);   /
 /* Several batches resident at once (bench: all inputs in HBM before the timed region). */
 int sw_probes_upload_slot(sw_engine* h, int slot, int level, int nb, const int8_t* probes);
 int sw_probes_select(sw_engine* h, int slot);
+/* Device-side probe generation (replaces np.random.randint(2, size=n) at utils.py:213-216,
+ * 255-258 for probes that never need to exist on the host).  The engine holds a window of the
+ * reference's MT19937 stream: sw_probes_stream_set() hands over the 624 raw state words at the
+ * stream position that becomes position 0 (sw_mt_window() below makes them from a seed or from a
+ * NumPy state); sw_probes_generate() fills `slot` with the nb probes whose first entry is draw
+ * number `pos` of that stream (one 32-bit draw per entry, bit-exact with NumPy), jumping there
+ * with GF(2) jump polynomials -- cost independent of `pos`.  Asynchronous on the engine stream. */
+#define SW_PROBES_Z2 1   /* entry = 2*(draw & 1) - 1              (the reference's probes)          */
+#define SW_PROBES_Z4 2   /* draw & 3 -> 1, i, -1, -i as 1,2,-1,-2  (build-only, BASELINE config 1)  */
+int sw_probes_stream_set(sw_engine* h, const uint32_t* window);
+int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint64_t pos);
+/* Copy the int8 codes held in `slot` (uploaded or generated) to the host: nb*n bytes. */
+int sw_probes_fetch(sw_engine* h, int slot, int8_t* out);
 int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter);
 int sw_sync(sw_engine* h);
 int sw_hutch_fetch(sw_engine* h, double* ests, int32_t* iters);
@@ -163,6 +176,18 @@ void sw_mt_destroy(sw_mt19937* g);
 void sw_mt_skip(sw_mt19937* g, uint64_t ndraws);
 void sw_mt_raw(sw_mt19937* g, uint64_t n, uint32_t* out);
 void sw_mt_rademacher(sw_mt19937* g, uint64_t n, int8_t* out);
+void sw_mt_z4(sw_mt19937* g, uint64_t n, int8_t* out);   /* codes 1,2,-1,-2 from draw & 3 */
+/* NumPy interchange: key[624] + pos exactly as np.random.get_state()[1:3]. */
+sw_mt19937* sw_mt_from_state(const uint32_t* key, int pos);
+void sw_mt_get_state(const sw_mt19937* g, uint32_t* key, int* pos);
+/* The 624 raw words starting at the current stream position (input of sw_probes_stream_set). */
+void sw_mt_window(sw_mt19937* g, uint32_t* out);
+/* Jump ahead by ndraws in O(1) state refills: g_J(x) = x^J mod phi(x) over GF(2) applied to the
+ * window (sw_mt_skip is the sequential checker).  sw_mt_jump_poly returns the 19937 coefficient
+ * bits of g_J in 624 words (bit i of the array = coefficient of x^i); non-zero = failure. */
+int sw_mt_jump(sw_mt19937* g, uint64_t ndraws);
+int sw_mt_jump_poly(uint64_t ndraws, uint32_t* poly);
+int sw_mt_window_jump(const uint32_t* window, uint64_t ndraws, uint32_t* out);
 
 #ifdef __cplusplus
 }

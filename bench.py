@@ -159,6 +159,16 @@ def run(args):
         A = None
         n_unknowns = 2 * Ls * Ls
     else:
+        config2 = args.workload == "config2"
+        if config2:
+            # BASELINE config 2 as written: plain Hutchinson, 2-level MG 32768 -> 8192 from the
+            # reference's own aggregation, dense coarse inverse; no solver hierarchy, no deflation
+            params['max_nr_levels'] = 2
+            params['nr_deflat_vctrs'] = 0
+            params['use_solver_hierarchy'] = False
+            params['ref_smoother'] = 'richardson'
+            params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "7"))
+            params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "12"))
         A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
         tp = utils.trace_params_from_params(params, "mlmc" if args.workload == "mlmc" else "hutchinson")
         mg = MG(A)
@@ -276,7 +286,10 @@ def run(args):
 
     if rank == 0:
         mean, std = swdist.mean_and_population_std(total)
-        levels = mg.solver_info["levels"] if mg.solver_info else [n]
+        if mg.solver_info:
+            levels = mg.solver_info["levels"]
+        else:
+            levels = [lev.A.shape[0] for lev in mg.ml.levels]
         nc = levels[-1]
         # algorithmic bytes / flops per launch
         algo = {
@@ -285,7 +298,7 @@ def run(args):
             "k_stencil<2>": ("hbm", V * (96.0 * nbp + 32.0)),              # fused smoother step
             "k_bsr_mfma(dense coarsest)": ("mfma", 8.0 * nc * nc * nbp),
             "k_bsr_mfma(level-1 operator)": ("mfma", 8.0 * levels[1] * 80.0 * nbp
-                                             if len(levels) > 1 else 0.0),
+                                             if len(levels) > 2 else 0.0),
         }
         peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (MFMA_F64_PEAK_TFLOPS, "TFLOP/s", 1e12)}
         pmc = {}
@@ -299,6 +312,9 @@ def run(args):
                 pmc = json.load(open(pmc_path))
             except Exception:
                 pmc = {}
+            if args.workload != "hutchinson":
+                # the MFMA kernels' PMC passes were taken on the default workload's operators
+                pmc = {k: v for k, v in pmc.items() if k.startswith("k_stencil")}
         rooflines = []
         for name, (ms_tot, cnt) in kstats.items():
             if cnt == 0:
@@ -319,6 +335,7 @@ def run(args):
         bytes0 = algo["k_stencil<0>"][1]
         out = {
             "metric": {"hutchinson": "hutchinson_probe_samples_per_sec_schwinger128",
+                       "config2": "hutchinson_probe_samples_per_sec_schwinger128",
                        "mlmc": "mlmc_level0_difference_probe_samples_per_sec_schwinger128",
                        "synthetic": "hutchinson_probe_samples_per_sec_synthetic%d" % L}[args.workload],
             "value": world * ne * args.steps * nb / elapsed,
@@ -342,8 +359,14 @@ def run(args):
             "config": {
                 "workload": "schwinger128, %d x %d probes/GPU/step (%d concurrent multi-RHS batches "
                             "of %d on separate HIP streams), deflated Hutchinson (k=8, Pperm shift "
-                            "512), fp64, tol %.0e" % (ne, nb, ne, nb, args.tol)
+                            "512), tuned 3-level solver hierarchy 32768/16384/4096, fp64, tol %.0e"
+                            % (ne, nb, ne, nb, args.tol)
                             if args.workload == "hutchinson" else
+                            "BASELINE config 2 as written: schwinger128, %d x %d probes/GPU/step as "
+                            "multi-RHS batches, plain Hutchinson (k=0, Pperm shift 512), 2-level "
+                            "multigrid 32768 -> 8192 (reference aggregation: 32-row aggregates, 4 test "
+                            "vectors x 2; dense 8192^2 coarse inverse on fp64 MFMA), fp64, tol %.0e"
+                            % (ne, nb, args.tol) if args.workload == "config2" else
                             "synthetic %dx%d random U(1) lattice (sigma 0.204, m -0.05), %d x %d plain "
                             "Hutchinson probes/GPU/step, GPU-side adaptive MG setup, fp64, tol %.0e"
                             % (L, L, ne, nb, args.tol) if synthetic else
@@ -352,7 +375,10 @@ def run(args):
                             "level skipping), fp64, tol %.0e" % (ne, nb, args.tol),
                 "probes_per_step_per_gpu": ne * nb,
                 "streams_per_gpu": ne,
-                "solver": mg.solver_info,
+                "solver": mg.solver_info if mg.solver_info else
+                {"levels": levels, "hierarchy": "reference (multigrid.py:100-345)",
+                 "smoother": tp.get("ref_smoother", "mr"), "nu_post": tp.get("ref_cycle_post", 4),
+                 "restart": tp.get("solver_restart", 24)},
                 "outer_iterations_max": max(iters_seen) if iters_seen else None,
                 "trace_estimate": [float(np.real(mean + tr1)), float(np.imag(mean + tr1))],
                 "std_dev": std,
@@ -370,7 +396,7 @@ def run(args):
         if not args.no_large_stencil and not synthetic:
             out["stencil_roofline_1024"] = large_stencil_point()
         if world == 1 and not args.no_cpu_baseline and args.workload == "hutchinson":  # 128^2 only
-            out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes)
+            out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes, args.cpu_workers)
         line_out = json.dumps(out)
     if td.is_initialized():
         comm.barrier()
@@ -399,33 +425,90 @@ def large_stencil_point(L=1024, nb=64, reps=20):
             "frac": ach / HBM_PEAK_GBS, "work_per_launch": work, "avg_launch_ms": ms}
 
 
-def cpu_baseline(A, tp, mg, nprobes):
-    """The oracle's reference-faithful path (SciPy CSR + lgmres(maxiter=2) smoother + flexible
-    GMRES, tol 1e-12, OMP_NUM_THREADS=1 as main.py:20 forces) on a bounded sample."""
+def _oracle_probe_loop(A, tp, testvectors, Ux, nprobes, seed):
+    """`nprobes` deflated Hutchinson probes through the oracle's reference-faithful path (SciPy
+    CSR + lgmres(maxiter=2) smoother + flexible GMRES, tol 1e-12); returns the loop's seconds.
+    The probe draw (np.random.randint, utils.py:213-216) is inside the timed loop, as the probe
+    generation is inside the GPU's timed region."""
     from oracle import ref_path as rp
     omg = rp.OracleMG(A)
     omg.setup(tp['dof'], tp['aggrs'], tp['max_nr_levels'], tp['accuracy_mg_eigvs'], tp,
-              testvectors=mg.testvectors)
-    lev0 = omg.ml.levels[0]
-    Ux, _, _, _ = rp.deflation_hutchinson(A, lev0.g3, lev0.Pperm, tp['nr_deflat_vctrs'],
-                                          tp['defl_eigvs_tol_Hutch'], True)
-    PT = lev0.Pperm.transpose()
+              testvectors=testvectors)
+    PT = omg.ml.levels[0].Pperm.transpose()
 
     def solve(b):
         omg.level_nr = 0
         omg.solve(A, b, tp['function_params']['tol'])
         return omg.x
 
-    np.random.seed(123456)
-    t0 = time.perf_counter()
-    for _ in range(nprobes):
-        rp.hutch_probe(rp.rademacher(A.shape[0]), solve, Ux, PT)
-    dt = time.perf_counter() - t0
-    return {"value": nprobes / dt, "unit": "probe-samples/s", "cores": 1, "kind": "port",
-            "sample": "%d deflated Hutchinson probes of the same workload (setup excluded), "
-                      "oracle/ref_path.py restatement of the reference path, 1 thread of %d host "
-                      "cores" % (nprobes, os.cpu_count() or 0),
-            "seconds": dt}
+    def loop():
+        np.random.seed(seed)
+        t0 = time.perf_counter()
+        for _ in range(nprobes):
+            rp.hutch_probe(rp.rademacher(A.shape[0]), solve, Ux, PT)
+        return time.perf_counter() - t0
+    return loop
+
+
+def _cpu_worker(A, tp, testvectors, Ux, nprobes, seed, barrier, queue):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    try:
+        loop = _oracle_probe_loop(A, tp, testvectors, Ux, nprobes, seed)
+        barrier.wait(timeout=600)
+        queue.put(loop())
+    except Exception as exc:      # the parent reports it
+        queue.put("error: %r" % (exc,))
+
+
+def cpu_baseline(A, tp, mg, nprobes, nworkers):
+    """The oracle's reference-faithful path on this host: the headline is
+    ONE core with OMP_NUM_THREADS=1 as main.py:20 forces; the second line uses the host's cores the
+    only way that helps this workload (threads inside SciPy/BLAS slow it down):
+    independent probes in `nworkers` single-threaded processes."""
+    from oracle import ref_path as rp
+    lev0_g3 = mg.ml.levels[0].g3
+    Ux, _, _, _ = rp.deflation_hutchinson(A, lev0_g3, mg.ml.levels[0].Pperm, tp['nr_deflat_vctrs'],
+                                          tp['defl_eigvs_tol_Hutch'], True)
+    tp_plain = {k: v for k, v in tp.items() if k not in ("mg_testvectors", "solver_testvectors")}
+    dt = _oracle_probe_loop(A, tp_plain, mg.testvectors, Ux, nprobes, 123456)()
+    out = {"value": nprobes / dt, "unit": "probe-samples/s", "cores": 1, "kind": "port",
+           "sample": "%d deflated Hutchinson probes of the same workload (probe draw included, setup "
+                     "excluded), oracle/ref_path.py restatement of the reference path, 1 thread of %d "
+                     "host cores" % (nprobes, os.cpu_count() or 0),
+           "seconds": dt}
+    if nworkers < 0:
+        nworkers = min(os.cpu_count() or 1, 16)
+    if nworkers > 1:
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")          # fresh interpreters: NumPy/SciPy only, no GPU
+        per = 2
+        barrier = ctx.Barrier(nworkers)
+        queue = ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker,
+                             args=(A, tp_plain, mg.testvectors, Ux, per, 1000 + w, barrier, queue))
+                 for w in range(nworkers)]
+        for pr in procs:
+            pr.start()
+        times = []
+        try:
+            for _ in procs:
+                r = queue.get(timeout=900)
+                if isinstance(r, str):
+                    raise RuntimeError(r)
+                times.append(r)
+            out["all_cores"] = {"value": nworkers * per / max(times), "unit": "probe-samples/s",
+                                "cores": nworkers, "kind": "port",
+                                "sample": "%d single-threaded processes x %d probes each (independent "
+                                          "probe streams), same path" % (nworkers, per),
+                                "seconds": max(times)}
+        except Exception as exc:
+            out["all_cores"] = {"error": repr(exc)}
+        finally:
+            for pr in procs:
+                pr.join(timeout=30)
+                if pr.is_alive():
+                    pr.terminate()
+    return out
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 // compute entry point fails with a message when no HIP device is present.
 #include "../../include/schwinger_hip.h"
 #include "sw_kernels.hpp"
+#include "sw_pack.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -301,80 +302,23 @@ static int stream_sync(sw_engine* h) {
 #define KLAUNCH_CHECK() HIPCHK(hipGetLastError())
 
 // ---------------------------------------------------------------------------------------------
-// CSR -> grouped ELL (host), SURVEY 3.4 block structure
+// CSR -> grouped ELL / MFMA block-row form: packed on the host (sw_pack.hpp), uploaded here
 // ---------------------------------------------------------------------------------------------
-// rows_int[r] = natural row stored at internal row r (empty: identity);
-// colmap[c]   = internal column of natural column c (empty: identity)
 static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_t* indptr,
                      const int32_t* indices, const std::complex<double>* data,
                      const std::vector<int>& rows_int, const std::vector<int>& colmap,
                      int forceG = 0) {
-  if (nrows <= 0 || ncols <= 0) return sw_fail(h, "build_ell: empty operator");
-  for (int r = 0; r < nrows; ++r) {
-    if (indptr[r + 1] < indptr[r]) return sw_fail(h, "build_ell: indptr not monotone");
-    for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q)
-      if (indices[q] < 0 || indices[q] >= ncols)
-        return sw_fail(h, "build_ell: column index %d out of range [0,%d)", indices[q], ncols);
-  }
-  auto natrow = [&](int r) { return rows_int.empty() ? r : rows_int[r]; };
-  auto icol = [&](int c) { return colmap.empty() ? c : colmap[c]; };
-  int bestG = 1;
-  int bestK = 0;
-  double bestCost = 1e300;
-  const int cand[5] = {16, 8, 4, 2, 1};
-  for (int ci = 0; ci < 5; ++ci) {
-    const int G = cand[ci];
-    if (forceG && G != forceG) continue;
-    if (nrows % G) continue;
-    int K = 0;
-    std::vector<int> u;
-    for (int g0 = 0; g0 < nrows; g0 += G) {
-      u.clear();
-      for (int g = 0; g < G; ++g) {
-        const int r = natrow(g0 + g);
-        for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) u.push_back(icol(indices[q]));
-      }
-      std::sort(u.begin(), u.end());
-      u.erase(std::unique(u.begin(), u.end()), u.end());
-      K = std::max(K, (int)u.size());
-    }
-    if (K == 0) K = 1;
-    const double cost = K * (1.0 / G + 0.25);
-    if (cost < bestCost) {
-      bestCost = cost;
-      bestG = G;
-      bestK = K;
-    }
-  }
-  const int G = bestG, K = bestK, ng = nrows / G;
-  std::vector<int> hc((size_t)ng * K, 0);
-  std::vector<std::complex<double>> hv((size_t)ng * K * G, std::complex<double>(0, 0));
-  std::vector<int> u;
-  for (int gi = 0; gi < ng; ++gi) {
-    u.clear();
-    for (int g = 0; g < G; ++g) {
-      const int r = natrow(gi * G + g);
-      for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) u.push_back(icol(indices[q]));
-    }
-    std::sort(u.begin(), u.end());
-    u.erase(std::unique(u.begin(), u.end()), u.end());
-    for (size_t k = 0; k < u.size(); ++k) hc[(size_t)gi * K + k] = u[k];
-    for (int g = 0; g < G; ++g) {
-      const int r = natrow(gi * G + g);
-      for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
-        const int c = icol(indices[q]);
-        const size_t k = std::lower_bound(u.begin(), u.end(), c) - u.begin();
-        hv[((size_t)gi * K + k) * G + g] += data[q];
-      }
-    }
-  }
+  swp::EllHost e;
+  std::string err;
+  if (swp::ell_pack(e, err, nrows, ncols, indptr, indices, data, rows_int, colmap, forceG) != 0)
+    return sw_fail(h, "%s", err.c_str());
   op.nrows = nrows;
   op.ncols = ncols;
-  op.K = K;
-  op.G = G;
-  op.ngroups = ng;
-  SWCHK(upload(h, &op.cols, hc.data(), hc.size()));
-  SWCHK(upload(h, (std::complex<double>**)&op.vals, hv.data(), hv.size()));
+  op.K = e.K;
+  op.G = e.G;
+  op.ngroups = e.ngroups;
+  SWCHK(upload(h, &op.cols, e.cols.data(), e.cols.size()));
+  SWCHK(upload(h, (std::complex<double>**)&op.vals, e.vals.data(), e.vals.size()));
   op.set = true;
   return 0;
 }
@@ -383,41 +327,13 @@ static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_
 // dense inverse).  Built only when at least `min_fill` of the packed 16x4 groups is non-zero.
 static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, const int32_t* indices,
                      const std::complex<double>* data, double min_fill) {
+  swp::BsrHost b;
+  swp::bsr_pack(b, n, indptr, indices, data, min_fill);
   op.bsr_KS = 0;
-  if (n % 16) return 0;
-  const int RT = n / 16;
-  std::vector<std::vector<int>> groups(RT);
-  int KS = 0;
-  for (int rt = 0; rt < RT; ++rt) {
-    std::vector<int>& g = groups[rt];
-    for (int r = rt * 16; r < rt * 16 + 16; ++r)
-      for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) g.push_back(indices[q] >> 2);
-    std::sort(g.begin(), g.end());
-    g.erase(std::unique(g.begin(), g.end()), g.end());
-    KS = std::max(KS, (int)g.size());
-  }
-  if (KS == 0) return 0;
-  KS += KS & 1;   // the kernel's two-stage pipeline wants an even number of k-steps
-  const double fill = (double)indptr[n] / ((double)RT * KS * 64.0);
-  if (fill < min_fill) return 0;
-  std::vector<int> kcol((size_t)RT * KS, 0);
-  std::vector<std::complex<double>> pk((size_t)RT * KS * 64, std::complex<double>(0, 0));
-  for (int rt = 0; rt < RT; ++rt) {
-    const std::vector<int>& g = groups[rt];
-    for (size_t k = 0; k < g.size(); ++k) kcol[(size_t)rt * KS + k] = g[k] * 4;
-    for (int i = 0; i < 16; ++i) {
-      const int r = rt * 16 + i;
-      for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
-        const int c = indices[q];
-        const size_t k = std::lower_bound(g.begin(), g.end(), c >> 2) - g.begin();
-        const int lane = i + 16 * (c & 3);
-        pk[((size_t)rt * KS + k) * 64 + lane] += data[q];
-      }
-    }
-  }
-  SWCHK(upload(h, &op.bsr_kcol, kcol.data(), kcol.size()));
-  SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, pk.data(), pk.size()));
-  op.bsr_KS = KS;
+  if (b.KS == 0) return 0;
+  SWCHK(upload(h, &op.bsr_kcol, b.kcol.data(), b.kcol.size()));
+  SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, b.vals.data(), b.vals.size()));
+  op.bsr_KS = b.KS;
   return 0;
 }
 
@@ -1003,7 +919,9 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     done += k;
     first = false;
     if (!outer) break;
-    if (converged && h->verify && done < maxiter) {
+    if (converged && h->verify) {
+      // (also at done == maxiter: a solve that is flagged converged on its last permitted
+      // iteration is still checked, and reported as not converged when the check fails)
       // true residual of every probe; continue when the Arnoldi recurrence was optimistic
       SWCHK(apply_op(h, lv, 1, X, B, ws.rres, nbp));
       PtrList pr;
@@ -1166,6 +1084,27 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
   SWCHK(free_op(h, H.cinv));
   H.nlevels = nlevels;
   H.ready = false;
+  if (hid == 0) {
+    // everything that was sized or indexed by the previous definition of the reference
+    // hierarchy: deflation vectors, permutations, rhs maps, probe slots and the probe workspace
+    h->kd = 0;
+    SWCHK(dev_free(h, h->U));
+    h->U = nullptr;
+    for (int l = 0; l < SW_MAX_LEVELS; ++l) {
+      h->lkd[l] = 0;
+      SWCHK(dev_free(h, h->lV[l]));
+      h->lV[l] = nullptr;
+      SWCHK(dev_free(h, h->perm_src[l]));
+      h->perm_src[l] = nullptr;
+      SWCHK(free_op(h, h->rhsmap[l]));
+    }
+    for (auto& sl : h->slots) SWCHK(dev_free(h, sl.p));
+    h->slots.clear();
+    h->pb_probes = nullptr;
+    h->pb_level = -1;
+    h->pb_nb = h->pb_nbp = 0;
+    h->pb_ws_nbp = 0;
+  }
   return 0;
 }
 

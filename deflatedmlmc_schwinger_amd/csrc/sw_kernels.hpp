@@ -1056,11 +1056,12 @@ __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
   if (col >= s.nbp) return;
   const int m = s.m, nbp = s.nbp;
   const double hn = sqrt(fmax(nrm2[col].x, 0.0));
-  s.scale[col] = cmake(hn > 0.0 ? 1.0 / hn : 0.0, 0.0);
   // apply the previous rotations
   cplx hk = cadd(h1[col], h2[col]);
+  double hcol2 = hk.x * hk.x + hk.y * hk.y;      // |h_{0..j,j}|^2 before the rotations
   for (int k = 0; k < j; ++k) {
     const cplx hk1 = cadd(h1[(size_t)(k + 1) * nbp + col], h2[(size_t)(k + 1) * nbp + col]);
+    hcol2 = fma(hk1.x, hk1.x, fma(hk1.y, hk1.y, hcol2));
     const double c = s.cs[(size_t)k * nbp + col].x;
     const cplx sn = s.sn[(size_t)k * nbp + col];
     // [ c  sn ; -conj(sn)  c ]
@@ -1098,11 +1099,20 @@ __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
   const cplx gn = s.g[(size_t)(j + 1) * nbp + col];
   const double nb_ = s.normb[col].x;
   const double rr = (nb_ > 0.0) ? sqrt(gn.x * gn.x + gn.y * gn.y) / nb_ : 0.0;
-  s.relres[col] = cmake(rr, 0.0);
+  const bool dead = (hn == 0.0 && hcol2 == 0.0);     // frozen earlier: w = 0, rr is meaningless
+  if (!dead) s.relres[col] = cmake(rr, 0.0);
   if (s.iters[col] < 0) {
     if (rr < tol) s.iters[col] = iter_base + j + 1;
     else atomicAdd(s.notconv, 1);
   }
+  // Next basis vector v_{j+1} = w / h_{j+1,j}.  Probes that have met tol keep iterating in
+  // lockstep with the batch (free extra accuracy) until they are two orders below it; then, or at
+  // (happy) breakdown h_{j+1,j} <= 1e-14 |A z_j| where the remainder is round-off that 1/h would
+  // blow up to a unit vector, the probe is FROZEN: scale 0 makes v_{j+1}, hence z, w and every
+  // later Hessenberg column of this probe exactly zero, and k_fg_solve gives y = 0 for them.
+  const bool frozen = (s.iters[col] >= 0 && rr < 1.0e-2 * tol) ||
+                      (hn * hn <= 1.0e-28 * (hcol2 + hn * hn));
+  s.scale[col] = cmake((hn > 0.0 && !frozen) ? 1.0 / hn : 0.0, 0.0);
 }
 
 // true-residual check after a solve: d[col].x = ||b - A x||^2; probes above tol are counted and

@@ -11,9 +11,26 @@ reference) and uploaded once:
   split, used only to precondition level-0 solves.  Converged solves do not depend on
   the preconditioner, so this is free to differ from the reference.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
+
+
+def dense_inverse(M):
+    """np.linalg.inv (multigrid.py:342-344).  The reference runs under OMP_NUM_THREADS=1
+    (main.py:20); a coarsest level of several thousand unknowns (BASELINE config 2: 8192) would take
+    minutes on one core, so large inversions borrow all host cores for the duration of the call."""
+    M = np.asarray(M)
+    if M.shape[0] >= 2048:
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=os.cpu_count() or 1):
+                return np.linalg.inv(M)
+        except ImportError:
+            pass
+    return np.linalg.inv(M)
 
 
 # ---------------------------------------------------------------------------------------
@@ -180,10 +197,8 @@ def prolongator_from_testvectors(tv, n, i, dof, aggrs):
 
 def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvectors=None):
     """multigrid.py:100-345 -> (SimpleML, coarsest_inv, testvectors)."""
-    if params["test_vectors_type"] not in ("EVs",):
-        if params["test_vectors_type"] in ("LSVs", "RSVs"):
-            raise Exception("test vectors of type %s are not supported by this build "
-                            "(the shipped presets use 'EVs')" % params["test_vectors_type"])
+    tv_type = params["test_vectors_type"]
+    if tv_type not in ("EVs", "LSVs", "RSVs"):
         raise Exception("unknown type of test vectors")
     if acc_eigvs == "low":
         tolx = 1.0e-3
@@ -210,10 +225,18 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
             ml.levels[0].Bblock_perm = sp.identity(n, dtype=np.complex128, format="csr")
         if testvectors is not None:
             tv = np.asarray(testvectors[i])
-        else:
+        elif tv_type == "EVs":
             ncv = nvec + 2 if acc_eigvs == "low" else None
             _, tv = spla.eigs(sp.csc_matrix(Al), k=nvec, which="LM", tol=tolx, maxiter=1000000,
                               sigma=0.0, ncv=ncv)
+        else:
+            # singular vectors through the hermitian Q = g3 A (multigrid.py:159-188): its
+            # eigenvectors are right singular vectors of A, g3 times them left singular vectors
+            Q = sp.csc_matrix(ml.levels[i].g3 @ Al)
+            _, tv = spla.eigsh(Q, k=nvec, which="LM", tol=tolx, sigma=0.0)
+            tv = tv.astype(np.complex128)
+            if tv_type == "LSVs":
+                tv[n // 2:] = -tv[n // 2:]
         used.append(tv)
         Pl = prolongator_from_testvectors(tv, n, i, dof, aggrs)
         Rl = sp.csr_matrix(Pl.conjugate().transpose())
@@ -229,7 +252,7 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
             nxt.Pperm = shift_operator(Pl.shape[1], sh)
             Bl = ml.levels[i].Pperm.transpose().conjugate() @ (Pl @ nxt.Pperm)
             nxt.Bblock_perm = sp.csr_matrix((Rl @ ml.levels[i].Bblock_perm) @ Bl)
-    coarsest_inv = np.matrix(np.linalg.inv(ml.levels[-1].A.toarray()))
+    coarsest_inv = np.matrix(dense_inverse(ml.levels[-1].A.toarray()))
     return ml, coarsest_inv, used
 
 
@@ -329,5 +352,5 @@ def solver_hierarchy(A0, L, cfg=None, testvectors=None):
         As.append(Ac)
         Lf //= agg
         hd = nvec
-    cinv = np.linalg.inv(As[-1].toarray())
+    cinv = dense_inverse(As[-1].toarray())
     return {"A": As, "P": Ps, "coarsest_inv": cinv, "tv": tvs, "cfg": cfg}

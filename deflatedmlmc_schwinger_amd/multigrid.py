@@ -50,6 +50,7 @@ class MG:
         self._A0 = A
         self._have_solver_hier = False
         self.maxiter_cap = 1000
+        self._ref_weights = {}
 
     # ------------------------------------------------------------------------------------
     def setup(self, dof=[2, 8, 8], aggrs=[2 * 2, 2 * 2], max_levels=3, dim=2, acc_eigvs='low',
@@ -135,8 +136,15 @@ class MG:
                     eng.set_csr(REF_HID, i, levels[i].A)
                 eng.set_transfer(REF_HID, i, levels[i].P)
                 # MR(nu) stands in for lgmres(maxiter=smooth_iters); see DESIGN.md section 4
-                eng.set_cycle(REF_HID, i, 0, int(params.get("ref_cycle_post", 4)) if params else 4,
+                nu_post = int(params.get("ref_cycle_post", 4)) if params else 4
+                eng.set_cycle(REF_HID, i, 0, nu_post,
                               int(params.get("ref_cycle_k", 0)) if params else 0)
+                if params and params.get("ref_smoother") == "richardson":
+                    # fixed polynomial instead of MR(nu) on the reference hierarchy's levels
+                    if ("ref", i, nu_post) not in self._ref_weights:
+                        self._ref_weights[("ref", i, nu_post)] = _hier.smoother_weights(levels[i].A,
+                                                                                        nu_post)
+                    eng.set_smoother(REF_HID, i, None, self._ref_weights[("ref", i, nu_post)])
             if nlev > 1:
                 eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A)
             eng.set_coarsest_inv(REF_HID, cinv)
@@ -152,7 +160,7 @@ class MG:
             self.upload_solver_hierarchy(cfg, params.get("solver_testvectors") if params else None)
         else:
             for eng in self.engines:
-                eng.set_solver(24, REF_HID)
+                eng.set_solver(int(params.get("solver_restart", 24)) if params else 24, REF_HID)
 
     def upload_solver_hierarchy(self, cfg=None, testvectors=None):
         """(Re)build the level-0 preconditioner hierarchy from `cfg` and make it the solver."""

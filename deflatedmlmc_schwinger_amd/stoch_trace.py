@@ -215,7 +215,10 @@ def hutchinson(A, params):
     result['total_complexity'] += levels[len(levels) - 1].A.nnz * mg_solver.coarsest_lev_iters[0]
     # stoch_trace.py:173-175 (hard-coded 1/3 kept)
     result['total_complexity'] += result['nr_ests'] * (2 * N * nr_deflat_vctrs) / 3.0
+    # build-only extras (not in the reference's dictionary)
     result['ests'] = loop["ests"]
+    result['rough_trace'] = rough_trace
+    result['level_tol'] = rough_trace_tol
     mg_solver.sync_timer()
     print(mg_solver.timer)
     return result
@@ -269,7 +272,7 @@ def mlmc(A, params):
     rough_trace = _rough_trace(mg_solver, params, N, Vx, tr1)
 
     output_params = {'nr_levels': nr_levels, 'trace': 0.0, 'total_complexity': 0.0,
-                     'std_dev': 0.0, 'results': []}
+                     'std_dev': 0.0, 'results': [], 'rough_trace': rough_trace}
     for i in range(nr_levels):
         output_params['results'].append({'function_iters': 0, 'nr_ests': 0, 'ests_avg': 0.0,
                                          'ests_dev': 0.0, 'level_complexity': 0.0})
@@ -318,7 +321,8 @@ def mlmc(A, params):
         res[i]['nr_ests'] += loop["index"]
         res[i]['ests_avg'] = loop["avg"] + tr1s[i]
         res[i]['ests_dev'] = loop["dev"]
-        res[i]['ests'] = loop["ests"]
+        res[i]['ests'] = loop["ests"]              # build-only extras
+        res[i]['level_tol'] = level_trace_tol
         print(" done. Time : " + str(time.time() - t0) + " seconds")
 
     # coarsest level, computed directly                            stoch_trace.py:418-437

@@ -36,3 +36,16 @@ def test_create_without_gpu_reports_error(lib_built):
     h = ctypes.c_void_p()
     assert lib_built.sw_create(ctypes.byref(h), 0) != 0
     assert b"no HIP device" in lib_built.sw_last_error(None)
+
+
+def test_host_code_under_address_and_ub_sanitizers():
+    """SURVEY section 5 (sanitizers): the host-side packers and the MT19937 / GF(2) jump code
+    build with -fsanitize=address,undefined and their driver runs clean (`make sanitize`)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host toolchain")
+    csrc = os.path.join(ROOT, "deflatedmlmc_schwinger_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "sanitize"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "all checks passed" in out.stdout

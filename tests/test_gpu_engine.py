@@ -208,7 +208,8 @@ def test_mlmc_probes_match_lu_oracle(p128):
     def solve_level(l, b):
         return p.lu_solver(l)(b)
 
-    for level, mode, skip in ((0, MODE_MLMC_SKIP, True), (2, MODE_MLMC, False), (0, MODE_MLMC, False)):
+    for level, mode, skip in ((0, MODE_MLMC_SKIP, True), (2, MODE_MLMC, False), (0, MODE_MLMC, False),
+                              (1, MODE_MLMC, False)):
         n = p.levels[level].A.shape[0]
         np.random.seed(1000 + level)
         probes = utils.draw_probes(6, n)
@@ -268,9 +269,32 @@ def test_bench_dirac_runs(p128):
 EXACT_128 = -8.748242701374695 + 50.215154098005584j      # gateway.py:100-104
 
 
+def _golden_rough_trace_128():
+    """stoch_trace.py:288-301: mean of the first five deflated probes of seed 123456 + tr1, from
+    the golden values the reference's own utils produced."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                    "golden.json")))
+    first5 = np.array([complex(a, b) for a, b in g["hutch128_deflated_k8_seed123456"][:5]])
+    return np.sum(first5) / 5 + complex(*g["defl128_tr1"])
+
+
+def _check_level_rule(r, tol, rough, tol_fctr):
+    """The stopping rule of stoch_trace.py:394-406 met ITS tolerance |tol * rough * tol_fctr| at
+    the reported index and at no earlier index >= 5."""
+    level_tol = abs(tol * rough * tol_fctr)
+    assert abs(r['level_tol'] - level_tol) < 1e-6 * level_tol
+    assert r['ests_dev'] / np.sqrt(r['nr_ests'] + 1) < level_tol
+    idx, avg, dev = rp.stopping_rule(np.asarray(r['ests']), r['level_tol'])
+    assert idx == r['nr_ests'] and len(r['ests']) == idx + 1
+    assert dev == r['ests_dev']
+
+
 def test_full_mlmc_flow_128_within_reported_error(capsys):
-    """BASELINE config 3 / G202: the drop-in mlmc() on schwinger128 with the shipped preset;
-    the trace must agree with the reference's exact value within the estimator's own error."""
+    """BASELINE config 3 / G202: the drop-in mlmc() on schwinger128 with the shipped preset
+    (4 levels, level 1 skipped): every difference level stops exactly where the reference's rule
+    stops for its tolerance share (sqrt(0.9), sqrt(0.1), stoch_trace.py:325-336,356-365), and the
+    trace agrees with the reference's exact value within the estimator's own error."""
     from deflatedmlmc_schwinger_amd import stoch_trace
     params = gateway.set_params('schwinger128')
     params['function_tol'] = 1e-12
@@ -279,6 +303,10 @@ def test_full_mlmc_flow_128_within_reported_error(capsys):
     res = stoch_trace.mlmc(A, tp)
     capsys.readouterr()
     assert res['nr_levels'] == 4
+    rough = _golden_rough_trace_128()
+    assert abs(res['rough_trace'] - rough) < 1e-7 * abs(rough)
+    _check_level_rule(res['results'][0], tp['tol'], rough, np.sqrt(0.9))
+    _check_level_rule(res['results'][2], tp['tol'], rough, np.sqrt(0.1))
     err2 = 0.0
     for i in (0, 2):
         r = res['results'][i]
@@ -287,10 +315,92 @@ def test_full_mlmc_flow_128_within_reported_error(capsys):
     assert res['results'][1]['nr_ests'] == 0            # skipped level
     assert res['results'][3]['nr_ests'] == 1            # direct coarsest term
     err = np.sqrt(err2)
+    # the rule bounds the combined error by |tol * rough| (0.9 + 0.1 of its square)
+    assert err < abs(tp['tol'] * rough)
     assert abs(res['trace'] - EXACT_128) < 4.0 * err + 1e-9, (res['trace'], err)
-    # the stopping rule works against tol*|rough trace| (5 noisy probes), so only sanity here
-    assert 0.0 < err < 0.2 * abs(EXACT_128)
     assert res['total_complexity'] > 0
+
+
+def test_full_mlmc_flow_128_without_level_skipping(capsys):
+    """The non-skip 4-level branch (mlmc_levels_to_skip = []; tolerance fractions 0.45 / 0.45 /
+    0.1, stoch_trace.py:325-336): difference levels 0, 1 and 2 plus the direct coarsest term."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    params['mlmc_levels_to_skip'] = []
+    params['trace_tol'] = 3.0e-2
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    res = stoch_trace.mlmc(A, tp)
+    capsys.readouterr()
+    rough = _golden_rough_trace_128()
+    err2 = 0.0
+    for i, fctr in ((0, np.sqrt(0.45)), (1, np.sqrt(0.45)), (2, np.sqrt(0.1))):
+        r = res['results'][i]
+        _check_level_rule(r, tp['tol'], rough, fctr)
+        assert r['function_iters'] > r['nr_ests']
+        err2 += r['ests_dev'] ** 2 / (r['nr_ests'] + 1)
+    assert res['results'][3]['nr_ests'] == 1
+    err = np.sqrt(err2)
+    assert err < abs(tp['tol'] * rough)
+    assert abs(res['trace'] - EXACT_128) < 4.0 * err + 1e-9, (res['trace'], err)
+
+
+def test_mlmc_inexact_01_deflation_16(capsys):
+    """defl_type = "inexact_01" (utils.py:177-182): V need not be eigenvectors, the low-rank part
+    tr1 = tr(V^H D V) is computed with the difference operator itself (engine solves), and
+    tr(D (I - V V^H)) + tr1 = tr(D) for ANY orthonormal V -- checked against exact LU here."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    from scipy.sparse.linalg import LinearOperator
+    p = Problem('schwinger16', 8)
+    tp = dict(p.tp)
+    tp['defl_type'] = 'inexact_01'
+    tp['defl_eigvs_tol_MLMC'] = 1.0e-2          # deliberately rough vectors
+    tp['diff_lev_op_tol'] = 1.0e-3
+    cinv = np.asarray(p.mg.coarsest_inv)
+    mg = p.mg
+    mg.skip_level = False
+    for lvl in (0, 1):
+        mg.level_for_diff_op = lvl
+        n = p.levels[lvl].A.shape[0]
+        lop = LinearOperator((n, n), dtype=np.complex128,
+                             matvec=lambda v: mg.diff_op_Q(np.array(v, dtype=np.complex128)))
+        Vx, Ux, tr1 = utils.deflation_pre_computations(p.A, 4, tp['defl_eigvs_tol_MLMC'], "mlmc",
+                                                       mg.timer, tp, mg, lop, level_nr=lvl)
+        capsys.readouterr()
+        # oracle: tr(V^H (A_f^-1 - P A_c^-1 R) V) with exact solves
+        lev = p.levels[lvl]
+        lc = lvl + 1
+        ref = 0.0
+        for i in range(4):
+            v = Vx[:, i]
+            t1 = p.lu_solver(lvl)(v)
+            vc = lev.R @ v
+            t2 = cinv @ vc if lc == len(p.levels) - 1 else p.lu_solver(lc)(vc)
+            ref += np.vdot(v, t1 - lev.P @ np.asarray(t2).reshape(-1))
+        assert abs(tr1 - ref) < 1e-9 * max(1.0, abs(ref)), (lvl, tr1, ref)
+        # probes with the projection registered by deflation_pre_computations
+        np.random.seed(900 + lvl)
+        probes = utils.draw_probes(4, n)
+        ests, _, _ = p.eng.hutch_batch(MODE_MLMC, lvl, probes, 1e-12, 1000)
+        for k in range(4):
+            refk = rp.mlmc_probe(probes[k].astype(np.complex128), lvl, p.levels, False,
+                                 lambda l, b: p.lu_solver(l)(b), cinv, False, Vx=Vx)
+            assert abs(ests[k] - refk) < 1e-9 * max(1.0, abs(refk))
+        p.eng.set_level_deflation(lvl, None)
+    # the whole flow: unbiased with inexact vectors
+    params = gateway.set_params('schwinger16')
+    params.update({'function_tol': 1e-12, 'nr_deflat_vctrs': 8, 'mlmc_deflat_vctrs': [4, 4],
+                   'defl_type': 'inexact_01', 'defl_eigvs_tol_MLMC': 1.0e-2,
+                   'trace_tol': 2.0e-2, 'mlmc_levels_to_skip': []})
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tpf = utils.trace_params_from_params(params, "mlmc")
+    tpf['batch'] = 64
+    res = stoch_trace.mlmc(A, tpf)
+    capsys.readouterr()
+    exact = 265.8581064657958
+    err2 = sum(res['results'][i]['ests_dev'] ** 2 / (res['results'][i]['nr_ests'] + 1) for i in (0, 1))
+    assert abs(res['trace'] - exact) < 4.0 * np.sqrt(err2) + 1e-6 * exact, (res['trace'], np.sqrt(err2))
 
 
 def test_full_deflated_hutchinson_flow_128_within_reported_error(capsys):

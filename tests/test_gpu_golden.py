@@ -1,0 +1,136 @@
+"""GPU parity straight against tests/golden/golden.json -- the values the REFERENCE's own
+utils.one_defl_Hutch_step / deflation_pre_computations produced (tests/golden/make_golden.py)
+with exact LU solves.  Tolerances: plain probes 1e-10 relative (north star); probes that go
+through ARPACK deflation vectors 1e-8 (the vectors themselves carry defl_eigvs_tol_Hutch = 1e-9
+on each side); MLMC differences 1e-10 relative to the minuend (difference of two O(100) numbers)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from deflatedmlmc_schwinger_amd import gateway, matrix, utils  # noqa: E402
+from deflatedmlmc_schwinger_amd.engine import (MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP)  # noqa: E402
+from deflatedmlmc_schwinger_amd.multigrid import MG  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+def _c(key):
+    return np.array([complex(a, b) for a, b in G[key]])
+
+
+def _setup(name, k_defl, overrides=None, testvectors=None):
+    params = gateway.set_params(name)
+    params['function_tol'] = 1e-12
+    params.update(overrides or {})
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    tp['mlmc_deflat_vctrs'] = [0] * 3
+    if testvectors is not None:
+        tp['mg_testvectors'] = testvectors
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs=tp['accuracy_mg_eigvs'], sys_type='schwinger', params=tp)
+    mg.total_levels = len(mg.ml.levels)
+    Ux, tr1 = utils.deflation_pre_computations(A, k_defl, 1e-9, "hutchinson", mg.timer, tp, mg)
+    return A, tp, mg, tr1
+
+
+def test_golden_128_plain_and_deflated_probes():
+    A, tp, mg, tr1 = _setup('schwinger128', 8)
+    n = A.shape[0]
+    # deflated (k = 8): golden made by the reference's own deflation code
+    gold_tr1 = complex(*G["defl128_tr1"])
+    assert abs(tr1 - gold_tr1) < 1e-8 * abs(gold_tr1)
+    np.random.seed(123456)
+    probes = utils.draw_probes(16, n)
+    assert probes[0][:16].tolist() == G["probe0_n32768_first16"]
+    ests, _, _ = mg.engine.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    gold = _c("hutch128_deflated_k8_seed123456")
+    assert np.max(np.abs(ests - gold) / np.abs(gold)) < 1e-8
+    # plain (k = 0): independent of hierarchy and eigenvectors
+    mg.engine.set_deflation(None)
+    ests, _, _ = mg.engine.hutch_batch(MODE_HUTCHINSON, 0, probes[:6], 1e-12, 1000)
+    gold = _c("hutch128_plain_seed123456")
+    assert np.max(np.abs(ests - gold) / np.abs(gold)) < 1e-10
+    # the same six probes generated on the device from the same stream
+    from deflatedmlmc_schwinger_amd.engine import ProbeStream
+    mg.engine.stream_set(ProbeStream(123456).window())
+    mg.engine.probes_generate(0, 0, 6, 0)
+    mg.engine.probes_select(0)
+    mg.engine.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
+    ests2, _, _ = mg.engine.hutch_fetch()
+    assert np.array_equal(ests2, ests)
+
+
+def test_golden_16_hutchinson_and_mlmc_levels():
+    tv = np.load(os.path.join(HERE, "golden", "schwinger16_testvectors.npz"))
+    A, tp, mg, tr1 = _setup('schwinger16', 8, {'accuracy_mg_eigvs': 'high'},
+                            testvectors=[tv["tv0"], tv["tv1"]])
+    n = A.shape[0]
+    gold_tr1 = complex(*G["defl16_tr1"])
+    assert abs(tr1 - gold_tr1) < 1e-8 * abs(gold_tr1)
+    np.random.seed(123456)
+    probes = utils.draw_probes(16, n)
+    ests, _, _ = mg.engine.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    gold = _c("hutch16_deflated_k8_seed123456")
+    assert np.max(np.abs(ests - gold) / np.abs(gold)) < 1e-8
+    mg.engine.set_deflation(None)
+    np.random.seed(123456)
+    probes = utils.draw_probes(32, n)
+    ests, _, _ = mg.engine.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    gold = _c("hutch16_plain_seed123456")
+    assert np.max(np.abs(ests - gold) / np.abs(gold)) < 1e-10
+    # MLMC difference levels 0 and 1 (no skipping) on the fixture's hierarchy
+    for lvl in (0, 1):
+        nl = mg.ml.levels[lvl].A.shape[0]
+        np.random.seed(4242 + lvl)
+        probes = utils.draw_probes(8, nl)
+        ests, _, _ = mg.engine.hutch_batch(MODE_MLMC, lvl, probes, 1e-12, 1000)
+        gold = _c("mlmc16_level%d_seed%d" % (lvl, 4242 + lvl))
+        # minuend x^H A_l^-1 x is O(n_l); the golden is a difference of two such numbers
+        scale = max(np.max(np.abs(gold)), float(nl) * 0.1)
+        assert np.max(np.abs(ests - gold)) / scale < 1e-10, lvl
+
+
+def test_golden_16_permuted_level_skipping():
+    tv = np.load(os.path.join(HERE, "golden", "schwinger16_testvectors.npz"))
+    A, tp, mg, _ = _setup('schwinger16', 0, {'accuracy_mg_eigvs': 'high', 'use_permuted': True,
+                                             'x_displacement': 1},
+                          testvectors=[tv["tv0"], tv["tv1"]])
+    n = A.shape[0]
+    np.random.seed(777)
+    probes = utils.draw_probes(8, n)
+    ests, _, _ = mg.engine.hutch_batch(MODE_MLMC_SKIP, 0, probes, 1e-12, 1000)
+    gold = _c("mlmc16_perm_skip_level0_seed777")
+    scale = max(np.max(np.abs(gold)), float(n) * 0.1)
+    assert np.max(np.abs(ests - gold)) / scale < 1e-10
+
+
+def test_config2_as_written_two_level_plain_hutchinson():
+    """BASELINE config 2 literally: schwinger128, plain (k = 0) Hutchinson, 2-level multigrid
+    32768 -> 8192 built with the reference's aggregation (multigrid.py:192-262: 32-row aggregates,
+    4 test vectors x 2), dense 8192^2 coarse inverse on the fp64 matrix cores.  Per-probe values
+    against the reference's own golden values (LU solves) at 1e-10."""
+    A, tp, mg, tr1 = _setup('schwinger128', 0, {'max_nr_levels': 2, 'use_solver_hierarchy': False,
+                                                'ref_smoother': 'richardson', 'ref_cycle_post': 7,
+                                                'solver_restart': 12})
+    assert [lev.A.shape[0] for lev in mg.ml.levels] == [32768, 8192]
+    assert tr1 == 0.0
+    n = A.shape[0]
+    np.random.seed(123456)
+    probes = utils.draw_probes(70, n)          # more than one 64-probe chunk
+    ests, itf, _ = mg.engine.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    gold = _c("hutch128_plain_seed123456")
+    assert np.max(np.abs(ests[:6] - gold) / np.abs(gold)) < 1e-10
+    assert 0 < int(itf.max()) < 200
+    # the dense 8192^2 inverse through the C ABI against NumPy
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((3, 8192)) + 1j * rng.standard_normal((3, 8192))
+    Y = mg.engine.coarsest(0, X)
+    ref = (np.asarray(mg.coarsest_inv) @ X.T).T
+    assert np.linalg.norm(Y - ref) / np.linalg.norm(ref) < 1e-12

@@ -274,3 +274,38 @@ def test_setup_cache_roundtrip_and_run_report(tmp_path, A16):
                                  "hutchinson", {"report_path": str(rep), "matrix": "x.mat"}, 2.0)
     assert rec["probe_samples_per_s"] == 5.0
     assert json.loads(rep.read_text().splitlines()[0])["trace"] == [1.0, 2.0]
+
+
+@pytest.mark.parametrize("tv_type", ["LSVs", "RSVs"])
+def test_singular_vector_test_vectors_give_a_g3_compatible_hierarchy(A16, tv_type):
+    """test_vectors_type LSVs / RSVs (multigrid.py:159-188): eigenvectors of Q = g3 A; the checks
+    are the reference's own check_quality_MG norms (multigrid.py:282-316)."""
+    p = gateway.set_params('schwinger16')
+    p['function_tol'] = 1e-12
+    p['test_vectors_type'] = tv_type
+    p['accuracy_mg_eigvs'] = 'high'
+    tp = utils.trace_params_from_params(p, "mlmc")
+    ml, cinv, tvs = hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], tp['max_nr_levels'],
+                                                  'high', tp)
+    assert len(ml.levels) == 3
+    for i in range(2):
+        lev, nxt = ml.levels[i], ml.levels[i + 1]
+        P = lev.P
+        nc = P.shape[1]
+        g3c = sp.diags([np.concatenate([np.ones(nc // 2), -np.ones(nc // 2)])], [0])
+        assert abs(lev.g3 @ P - P @ g3c).max() < 1e-13            # gamma3-compatibility
+        PhP = (P.conjugate().transpose() @ P).toarray()
+        assert np.abs(PhP - np.eye(nc)).max() < 1e-10             # single CGS sweep: 1e-11-ish
+        Qc = (g3c @ nxt.A).toarray()
+        assert np.abs(Qc - Qc.conj().T).max() < 1e-12             # g3 A_c hermitian
+    # the singular vectors themselves: Q v = lambda v  with |lambda| the smallest singular values
+    n = A16.shape[0]
+    g3 = ml.levels[0].g3
+    v = tvs[0][:, 0].copy()
+    if tv_type == "LSVs":
+        v[n // 2:] = -v[n // 2:]                                   # back to the eigenvector of Q
+    Qv = g3 @ (A16 @ v)
+    lam = np.vdot(v, Qv) / np.vdot(v, v)
+    assert np.linalg.norm(Qv - lam * v) < 1e-7 * np.linalg.norm(v)
+    smin = np.linalg.svd(A16.toarray(), compute_uv=False)[-1]
+    assert abs(abs(lam) - smin) < 1e-6 * smin + 1e-9 or abs(lam) < 10 * smin

@@ -167,8 +167,8 @@ def run(args):
             params['nr_deflat_vctrs'] = 0
             params['use_solver_hierarchy'] = False
             params['ref_smoother'] = 'richardson'
-            params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "7"))
-            params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "12"))
+            params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "48"))
+            params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "16"))
         A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
         tp = utils.trace_params_from_params(params, "mlmc" if args.workload == "mlmc" else "hutchinson")
         mg = MG(A)

@@ -29,6 +29,9 @@ class Comm:
     def broadcast_arrays(self, arrays, src=0):
         return arrays
 
+    def compute_on_root(self, fn):
+        return fn()
+
     def allreduce_stats(self, stats):
         return np.asarray(stats, dtype=np.float64)
 
@@ -119,6 +122,14 @@ class TorchComm(Comm):
             td.broadcast(t, src=src)
             out.append(t.cpu().numpy().view(a.dtype).reshape(a.shape))
         return out
+
+    def compute_on_root(self, fn, src=0):
+        """Setup operands that must be IDENTICAL on every rank (ARPACK test vectors, deflation
+        eigenpairs: an iterative eigensolver is not guaranteed bit-reproducible across processes):
+        rank `src` computes fn(), every rank returns rank `src`'s result, byte for byte."""
+        box = [fn() if self.rank == src else None]
+        self._td.broadcast_object_list(box, src=src)
+        return box[0]
 
     def allreduce_stats(self, stats):
         torch, td = self._torch, self._td

@@ -11,6 +11,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import cache as _cache
+from . import dist as _dist
 from . import hierarchy as _hier
 from .engine import Engine, EngineError
 from .hierarchy import LevelML, SimpleML  # noqa: F401  (re-exported, multigrid.py:26-48)
@@ -18,6 +19,26 @@ from .utils import CustomTimer
 
 REF_HID = 0      # reference hierarchy (MLMC level operators)
 SOLVER_HID = 1   # level-0 preconditioner hierarchy
+
+
+def collective_reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, tv=None,
+                                   comm=None):
+    """hierarchy.reference_hierarchy for one or several ranks: with more than one rank, rank 0
+    runs ARPACK and every rank builds the hierarchy from rank 0's test vectors (an iterative
+    eigensolver is not guaranteed to be bit-reproducible across processes, and the MLMC level
+    operators must be identical on all ranks)."""
+    comm = comm or _dist.default_comm()
+    built = None
+    if tv is None and comm.world > 1:
+        def root_build():
+            nonlocal built
+            built = _hier.reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params)
+            return built[2]
+        tv = comm.compute_on_root(root_build)
+    if built is None:
+        built = _hier.reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params,
+                                          testvectors=tv)
+    return built
 
 
 class MG:
@@ -68,8 +89,8 @@ class MG:
             if hit is not None:
                 tv = [hit["tv%d" % i] for i in range(max_levels - 1)]
                 ckey = None
-        ml, cinv, used = _hier.reference_hierarchy(self._A0, dof, aggrs, max_levels, acc_eigvs,
-                                                   params, testvectors=tv)
+        ml, cinv, used = collective_reference_hierarchy(self._A0, dof, aggrs, max_levels,
+                                                        acc_eigvs, params, tv)
         if ckey is not None:
             _cache.save(cdir, "mgtv", ckey, {"tv%d" % i: np.asarray(v) for i, v in enumerate(used)})
         self._cache_dir = cdir
@@ -186,15 +207,29 @@ class MG:
             if hit is not None:
                 testvectors = [hit["tv%d" % i] for i in range(len(cfg["coarsening"]))]
                 skey = None
-        if cfg.get("setup", "eigs") == "adaptive" and testvectors is None:
-            from . import setup_gpu
-            A0 = self.ml.levels[0].A
-            if A0 is None:
-                A0 = _hier.wilson_from_links(lat[2], lat[3], lat[0]) + \
-                    lat[1] * sp.identity(2 * lat[0] * lat[0], dtype=np.complex128, format="csr")
-            sh = setup_gpu.adaptive_solver_hierarchy(self.engines[0], A0, lat, cfg, SOLVER_HID)
-        else:
-            sh = _hier.solver_hierarchy(self.ml.levels[0].A, L, cfg, testvectors=testvectors)
+        comm = _dist.default_comm()
+        A0 = self.ml.levels[0].A
+        if A0 is None:
+            A0 = _hier.wilson_from_links(lat[2], lat[3], lat[0]) + \
+                lat[1] * sp.identity(2 * lat[0] * lat[0], dtype=np.complex128, format="csr")
+        adaptive = cfg.get("setup", "eigs") == "adaptive"
+
+        def build(tvs):
+            if adaptive and tvs is None:
+                from . import setup_gpu
+                return setup_gpu.adaptive_solver_hierarchy(self.engines[0], A0, lat, cfg, SOLVER_HID)
+            return _hier.solver_hierarchy(A0, L, cfg, testvectors=tvs)
+
+        sh = None
+        if testvectors is None and comm.world > 1:
+            # test vectors from ONE rank (ARPACK / the adaptive GPU setup), identical everywhere
+            def root_build():
+                nonlocal sh
+                sh = build(None)
+                return sh["tv"]
+            testvectors = comm.compute_on_root(root_build)
+        if sh is None:
+            sh = build(testvectors)
         nl = len(sh["A"])
         if skey is not None:
             _cache.save(cdir, "solvertv", skey, {"tv%d" % i: np.asarray(v) for i, v in enumerate(sh["tv"])})

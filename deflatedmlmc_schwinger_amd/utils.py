@@ -6,6 +6,7 @@ import time
 import numpy as np
 from scipy.sparse.linalg import eigsh
 
+from . import dist as _dist
 from .engine import MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP, EngineError
 
 
@@ -163,12 +164,15 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
                 Sy, Vx = hit["S"], hit["V"]
             else:
                 Q = (lev0.g3 * A).tocsc()                               # utils.py:137-140
-                Sy, Vx = eigsh(Q, k=nr_deflat_vctrs, which='LM', tol=tolx, sigma=0.0)
+                # (with several ranks: rank 0's eigenpairs everywhere, see dist.compute_on_root)
+                Sy, Vx = _dist.default_comm().compute_on_root(
+                    lambda: eigsh(Q, k=nr_deflat_vctrs, which='LM', tol=tolx, sigma=0.0))
                 if cdir:
                     _cache.save(cdir, "defl", ckey, {"S": Sy, "V": Vx})
     else:
         mg_solver.solve_tol = params['diff_lev_op_tol']                 # utils.py:142-143
-        Sy, Vx = eigsh(lop, k=nr_deflat_vctrs, which='LM', tol=tolx)
+        Sy, Vx = _dist.default_comm().compute_on_root(
+            lambda: eigsh(lop, k=nr_deflat_vctrs, which='LM', tol=tolx))
     sgn = np.where(Sy > 0, 1.0, -1.0)
     Sabs = Sy * sgn
     Ux = Vx * sgn[None, :]

@@ -83,3 +83,74 @@ def test_two_rank_probe_loop_equals_single_process():
         mean, std = dist.mean_and_population_std(stats)
         assert abs(mean - ref["avg"]) < 1e-9 * abs(ref["avg"])
         assert abs(std - ref["dev"]) < 1e-9 * ref["dev"]
+
+
+def _sha(arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode() + a.tobytes())
+    return h.hexdigest()
+
+
+def _worker_setup_and_mlmc(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from deflatedmlmc_schwinger_amd import dist, gateway, matrix, multigrid, stoch_trace, utils
+    from oracle import ref_path as rp
+    comm = dist.TorchComm()
+    # 1. compute_on_root: every rank ends with rank 0's bytes even when the local results differ
+    mine = np.random.default_rng(100 + rank).standard_normal((7, 3)) + 1j * rank
+    got = comm.compute_on_root(lambda: (mine, {"k": mine[:2].copy()}))
+    sha_bcast = _sha([got[0], got[1]["k"]])
+    # 2. the collective hierarchy build: test vectors from rank 0, operators identical
+    p = gateway.set_params('schwinger16')
+    p['function_tol'] = 1e-12
+    A = matrix.loadMatrix(p['matrix'], p['matrix_params'])
+    tp = utils.trace_params_from_params(p, "mlmc")
+    ml, cinv, used = multigrid.collective_reference_hierarchy(A, tp['dof'], tp['aggrs'],
+                                                              tp['max_nr_levels'], 'high', tp,
+                                                              comm=comm)
+    ops = list(used) + [np.asarray(cinv)]
+    for lev in ml.levels[:-1]:
+        for M in (lev.P.tocsr(), lev.A.tocsr()):
+            ops += [M.indptr, M.indices, M.data]
+    sha_hier = _sha(ops)
+    # 3. the MLMC branch of the probe loop (level-0 difference, exact host evaluator)
+    cinv_a = np.asarray(cinv)
+    lus = {l: rp.LUSolver(ml.levels[l].A) for l in range(2)}
+
+    def evaluate(probes):
+        e = np.array([rp.mlmc_probe(x.astype(np.complex128), 0, ml.levels, False,
+                                    lambda l, b: lus[l](b), cinv_a, False) for x in probes])
+        return e, np.full(len(e), 5), np.full(len(e), 2)
+    np.random.seed(4242)
+    out = stoch_trace.run_probe_loop(evaluate, A.shape[0], 0.35, 100000, 8, comm=comm)
+    q.put((rank, sha_bcast, sha_hier, out["index"], complex(out["avg"]), float(out["dev"]),
+           out["ests"].tolist(), int(out["iters_coarse"].sum()), int(np.random.randint(1 << 30))))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_share_setup_operands_and_replay_mlmc_branch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_setup_and_mlmc, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = results
+    assert r0[1] == r1[1]                 # broadcast object: byte-identical
+    assert r0[2] == r1[2]                 # test vectors, P, A, coarsest inverse: byte-identical
+    assert r0[3:] == r1[3:]               # MLMC loop: same stop index, stats, values, stream position
+    assert r0[3] >= 5 and r0[7] == 2 * (r0[3] + 1)

@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
+    ap.add_argument("--engine-opts", type=str, default=os.environ.get("SW_ENGINE_OPTS", ""),
+                    help="comma-separated name=value engine switches (sw_set_option) for A/B runs")
     ap.add_argument("--cpu-probes", type=int, default=8)
     ap.add_argument("--cpu-workers", type=int, default=-1,
                     help="processes of the all-cores CPU baseline line (-1: min(cores, 16); 0: skip)")
@@ -192,6 +194,9 @@ def run(args):
     # the window at stream position 0 and jumps to its own block of every round -------------------
     engs = mg.engines
     ne = len(engs)
+    for kv in [x for x in args.engine_opts.split(",") if x]:
+        for e_ in engs:
+            e_.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     window0 = ProbeStream(123456).window()
     for e in range(ne):
         engs[e].stream_set(window0)

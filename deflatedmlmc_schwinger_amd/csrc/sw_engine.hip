@@ -54,6 +54,7 @@ struct EllOp {
   int nrows = 0, ncols = 0, K = 0, G = 1, ngroups = 0;
   int* cols = nullptr;
   cplx* vals = nullptr;
+  int* order = nullptr;     // processing order of the row groups (NULL: natural), sw_pack.hpp
   bool set = false;
   // optional MFMA block-row form (square operators with n % 16 == 0 and dense-ish 16x4 blocks)
   int bsr_KS = 0;
@@ -63,13 +64,14 @@ struct EllOp {
 
 struct KrylovWS {
   int m = 0, n = 0, nbp = 0;
-  cplx* V = nullptr;  // (m+1) vectors
+  cplx* V = nullptr;  // m vectors: vtilde_1 .. vtilde_m (vtilde_0 is the residual itself)
   cplx* Z = nullptr;  // m vectors
   cplx* xacc = nullptr;
   cplx* rres = nullptr;
   swk::FgScalars sc{};
   cplx* h1 = nullptr;   // [(m+2)][nbp]
   cplx* h2 = nullptr;   // [(m+2)][nbp]
+  cplx* c1 = nullptr;   // [(m+2)][nbp] orthogonalisation coefficients svec_k^2 d_k
   cplx* nrm = nullptr;  // [nbp]
 };
 
@@ -114,6 +116,11 @@ struct sw_engine {
   int restart = 24;
   int solver_hid = 0;
   bool use_mfma = true;
+  int bsr_map = 1, bsr_sub = 8, dense_map = 0;   // block orderings of k_bsr_mfma (see the kernel)
+  bool bsr_nt = true;     // non-temporal B loads / Y stores in k_bsr_mfma on level operators
+  bool ell_order = true;   // visit prolongator row groups sorted by column (A/B switch)
+  int bench_what = 0;      // what sw_bench_dirac times: 0 operator, 1 restrict, 2 prolong, 3 coarsest inverse
+  int bench_mode = 0;      // operator mode sw_bench_dirac times (0: Y=AX, 1: residual, 2: smoother step)
   bool mfma_ops = true;   // MFMA block-row kernel also for block-structured level operators
   int mfma_tiles = 4;
   // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
@@ -307,10 +314,11 @@ static int stream_sync(sw_engine* h) {
 static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_t* indptr,
                      const int32_t* indices, const std::complex<double>* data,
                      const std::vector<int>& rows_int, const std::vector<int>& colmap,
-                     int forceG = 0) {
+                     int forceG = 0, bool sort_by_column = false) {
   swp::EllHost e;
   std::string err;
-  if (swp::ell_pack(e, err, nrows, ncols, indptr, indices, data, rows_int, colmap, forceG) != 0)
+  if (swp::ell_pack(e, err, nrows, ncols, indptr, indices, data, rows_int, colmap, forceG,
+                    sort_by_column) != 0)
     return sw_fail(h, "%s", err.c_str());
   op.nrows = nrows;
   op.ncols = ncols;
@@ -319,6 +327,7 @@ static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_
   op.ngroups = e.ngroups;
   SWCHK(upload(h, &op.cols, e.cols.data(), e.cols.size()));
   SWCHK(upload(h, (std::complex<double>**)&op.vals, e.vals.data(), e.vals.size()));
+  if (!e.order.empty()) SWCHK(upload(h, &op.order, e.order.data(), e.order.size()));
   op.set = true;
   return 0;
 }
@@ -340,6 +349,7 @@ static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, cons
 static int free_op(sw_engine* h, EllOp& op) {
   SWCHK(dev_free(h, op.cols));
   SWCHK(dev_free(h, op.vals));
+  SWCHK(dev_free(h, op.order));
   SWCHK(dev_free(h, op.bsr_kcol));
   SWCHK(dev_free(h, op.bsr_vals));
   op = EllOp();
@@ -353,15 +363,23 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
                       int nbp, int cat, cplx w) {
   const int RT = op.nrows / 16;
   const int NT = h->mfma_tiles;   // MFMA column tiles per wave (8 probes each)
-  dim3 grid((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, (2 * nbp) / (16 * NT));
+  dim3 grid(((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK) * ((2 * nbp) / (16 * NT)));
+  const int bmap = (cat == T_COARSEST) ? h->dense_map : h->bsr_map, msub = h->bsr_sub;
   LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE : (cat == T_MVM ? T_MFMA_OP : cat));
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
 #define BSR_LAUNCH(MD, NTT)                                                                     \
-  hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT>), grid, dim3(SW_BLOCK), 0, h->stream,            \
-                     (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, Yr, \
-                     2 * nbp, nbp, w)
+  do {                                                                                          \
+    if (h->bsr_nt && cat != T_COARSEST)                                                         \
+      hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, true>), grid, dim3(SW_BLOCK), 0, h->stream,  \
+                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, \
+                         Yr, 2 * nbp, nbp, w, bmap, msub);                                      \
+    else                                                                                        \
+      hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, false>), grid, dim3(SW_BLOCK), 0, h->stream, \
+                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, \
+                         Yr, 2 * nbp, nbp, w, bmap, msub);                                      \
+  } while (0)
   if (NT == 8) {
     if (mode == 0) BSR_LAUNCH(0, 8);
     else if (mode == 1) BSR_LAUNCH(1, 8);
@@ -388,16 +406,16 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   case GG:                                                                                      \
     if (mode == 0)                                                                              \
       hipLaunchKernelGGL((swk::k_ell<GG, 0>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, (const int*)(h->ell_order ? op.order : nullptr), X, B, Y, nbp, w);      \
     else if (mode == 1)                                                                         \
       hipLaunchKernelGGL((swk::k_ell<GG, 1>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, (const int*)(h->ell_order ? op.order : nullptr), X, B, Y, nbp, w);      \
     else if (mode == 2)                                                                         \
       hipLaunchKernelGGL((swk::k_ell<GG, 2>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, (const int*)(h->ell_order ? op.order : nullptr), X, B, Y, nbp, w);      \
     else                                                                                        \
       hipLaunchKernelGGL((swk::k_ell<GG, 3>), grid, dim3(SW_BLOCK), 0, h->stream, op.cols,      \
-                         op.vals, op.K, op.ngroups, X, B, Y, nbp, w);      \
+                         op.vals, op.K, op.ngroups, (const int*)(h->ell_order ? op.order : nullptr), X, B, Y, nbp, w);      \
     break;
   switch (op.G) {
     ELL_CASE(1)
@@ -489,7 +507,7 @@ static void row_blocking(int n, int nbp, bool reduce, int* P, int* rpb) {
 
 // out[k][col] = sum_r conj(V_k[r]) W[r],  k < K
 static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n, int nbp,
-                    cplx* out) {
+                    cplx* out, const cplx* svec = nullptr, cplx* coef = nullptr) {
   if (K < 1 || K > SW_MAXM + 2) return sw_fail(h, "multidot: K=%d out of range", K);
   int P, rpb;
   row_blocking(n, nbp, true, &P, &rpb);
@@ -512,7 +530,7 @@ static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n,
   {
     LaunchScope ls(h, T_DOTS);
     hipLaunchKernelGGL(swk::k_reduce_partials, dim3(K, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
-                       h->partial, P, K, nbp, out);
+                       h->partial, P, K, nbp, out, svec, coef);
     KLAUNCH_CHECK();
   }
   return 0;
@@ -549,19 +567,9 @@ static int multiaxpy(sw_engine* h, const PtrList& V, int K, const cplx* coef, do
   if (nrm_out) {
     LaunchScope ls(h, T_DOTS);
     hipLaunchKernelGGL(swk::k_reduce_partials, dim3(1, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
-                       h->partial, P, 1, nbp, nrm_out);
+                       h->partial, P, 1, nbp, nrm_out, (const cplx*)nullptr, (cplx*)nullptr);
     KLAUNCH_CHECK();
   }
-  return 0;
-}
-
-static int scale_to(sw_engine* h, const cplx* s, const cplx* src, cplx* dst, int n, int nbp) {
-  int P, rpb;
-  row_blocking(n, nbp, false, &P, &rpb);
-  LaunchScope ls(h, T_AXPY);
-  hipLaunchKernelGGL(swk::k_scale, dim3(P, nbp / 64), dim3(SW_BLOCK), 0, h->stream, s, src, dst, n,
-                     nbp, rpb);
-  KLAUNCH_CHECK();
   return 0;
 }
 
@@ -615,7 +623,9 @@ static int free_krylov(sw_engine* h, KrylovWS& w) {
   SWCHK(dev_free(h, w.sc.y)); w.sc.y = nullptr;
   SWCHK(dev_free(h, w.sc.normb)); w.sc.normb = nullptr;
   SWCHK(dev_free(h, w.sc.relres)); w.sc.relres = nullptr;
-  SWCHK(dev_free(h, w.sc.scale)); w.sc.scale = nullptr;
+  SWCHK(dev_free(h, w.sc.svec)); w.sc.svec = nullptr;
+  SWCHK(dev_free(h, w.sc.ys)); w.sc.ys = nullptr;
+  SWCHK(dev_free(h, w.c1)); w.c1 = nullptr;
   SWCHK(dev_free(h, w.sc.iters)); w.sc.iters = nullptr;
   SWCHK(dev_free(h, w.h1)); w.h1 = nullptr;
   SWCHK(dev_free(h, w.h2)); w.h2 = nullptr;
@@ -628,7 +638,7 @@ static int ensure_krylov(sw_engine* h, KrylovWS& w, int m, int n, int nbp, bool 
   if (w.m == m && w.n == n && w.nbp == nbp && w.V) return 0;
   SWCHK(free_krylov(h, w));
   const size_t vec = (size_t)n * nbp;
-  SWCHK(dev_realloc(h, &w.V, vec * (m + 1)));
+  SWCHK(dev_realloc(h, &w.V, vec * m));
   SWCHK(dev_realloc(h, &w.Z, vec * m));
   if (outer) {
     SWCHK(dev_realloc(h, &w.xacc, vec));
@@ -641,7 +651,9 @@ static int ensure_krylov(sw_engine* h, KrylovWS& w, int m, int n, int nbp, bool 
   SWCHK(dev_realloc(h, &w.sc.y, (size_t)m * nbp));
   SWCHK(dev_realloc(h, &w.sc.normb, (size_t)nbp));
   SWCHK(dev_realloc(h, &w.sc.relres, (size_t)nbp));
-  SWCHK(dev_realloc(h, &w.sc.scale, (size_t)nbp));
+  SWCHK(dev_realloc(h, &w.sc.svec, (size_t)(m + 1) * nbp));
+  SWCHK(dev_realloc(h, &w.sc.ys, (size_t)m * nbp));
+  SWCHK(dev_realloc(h, &w.c1, (size_t)(m + 2) * nbp));
   SWCHK(dev_realloc(h, &w.sc.iters, (size_t)nbp));
   SWCHK(dev_realloc(h, &w.h1, (size_t)(m + 2) * nbp));
   SWCHK(dev_realloc(h, &w.h2, (size_t)(m + 2) * nbp));
@@ -862,27 +874,29 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
                          first ? 1 : 0, tol);
       KLAUNCH_CHECK();
     }
-    SWCHK(scale_to(h, ws.sc.scale, Rcur, ws.V, n, nbp));
+    // the basis is kept unnormalised (k_fg_hess): vtilde_0 is the residual where it lies,
+    // vtilde_{j+1} the orthogonalised A M vtilde_j -- no normalisation passes over the vectors
+    auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
     int j = 0;
     const int jmax = std::min(m, maxiter - done);
     for (; j < jmax; ++j) {
-      cplx* vj = ws.V + vec * j;
+      const cplx* vj = vt(j);
       cplx* zj = ws.Z + vec * j;
-      cplx* w = ws.V + vec * (j + 1);
+      cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
       if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
       else SWCHK(copy_vec(h, zj, vj, n, nbp));
       SWCHK(apply_op(h, lv, 0, zj, nullptr, w, nbp));
       PtrList pv;
-      for (int k = 0; k <= j; ++k) pv.p[k] = ws.V + vec * k;
-      // pass 1: h1 = V^H w ; w -= V h1
-      SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h1));
+      for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
+      // pass 1: raw dots d1 = Vt^H w, coefficients c = svec^2 d1 ; w -= Vt c
+      SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1));
       if (h->cgs2 || !outer) {
-        SWCHK(multiaxpy(h, pv, j + 1, ws.h1, -1.0, w, w, n, nbp, nullptr));
-        // pass 2 (re-orthogonalisation): h2 = V^H w ; w -= V h2 ; ||w||^2
-        SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2));
-        SWCHK(multiaxpy(h, pv, j + 1, ws.h2, -1.0, w, w, n, nbp, ws.nrm));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, nullptr));
+        // pass 2 (re-orthogonalisation): d2 = Vt^H w ; w -= Vt (svec^2 d2) ; ||w||^2
+        SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2, ws.sc.svec, ws.c1));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm));
       } else {
-        SWCHK(multiaxpy(h, pv, j + 1, ws.h1, -1.0, w, w, n, nbp, ws.nrm));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm));
         HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
       }
       if (outer) HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
@@ -892,7 +906,6 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
                            ws.nrm, tol, done);
         KLAUNCH_CHECK();
       }
-      SWCHK(scale_to(h, ws.sc.scale, w, w, n, nbp));
       // read the flag back from the hinted iteration on, at the end of the budget, and in any
       // case every 8th iteration (a stale hint must never cost more than a few iterations)
       if (outer && (done + j + 1 >= check_from || done + j + 1 >= maxiter ||
@@ -915,7 +928,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     }
     PtrList pz;
     for (int q = 0; q < k; ++q) pz.p[q] = ws.Z + vec * q;
-    SWCHK(multiaxpy(h, pz, k, ws.sc.y, 1.0, X, X, n, nbp, nullptr));
+    SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n, nbp, nullptr));
     done += k;
     first = false;
     if (!outer) break;
@@ -1174,7 +1187,7 @@ int sw_set_transfer(sw_engine* h, int hid, int level, int n_f, int n_c, const in
     for (int i = 0; i < n_f; ++i) rows_int[lf.h_rowmap[i]] = i;
   }
   std::vector<int> none;
-  SWCHK(build_ell(h, lf.P, n_f, n_c, indptr, indices, cd, rows_int, none));
+  SWCHK(build_ell(h, lf.P, n_f, n_c, indptr, indices, cd, rows_int, none, 0, true));
   // R = P^H as CSR (rows = coarse), columns mapped to the fine internal order
   const int64_t nnz = indptr[n_f];
   std::vector<int64_t> rp(n_c + 1, 0);
@@ -1302,6 +1315,36 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (!h || !name) return 1;
   if (std::strcmp(name, "use_mfma") == 0) {
     h->use_mfma = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "bsr_map") == 0 || std::strcmp(name, "dense_map") == 0 ||
+      std::strcmp(name, "bsr_sub") == 0) {
+    const int v = (int)value;
+    if (name[4] == 's') {
+      if (v < 1) return sw_fail(h, "bsr_sub must be >= 1");
+      h->bsr_sub = v;
+    } else {
+      if (v < 0 || v > 2) return sw_fail(h, "%s must be 0, 1 or 2", name);
+      (name[0] == 'd' ? h->dense_map : h->bsr_map) = v;
+    }
+    return 0;
+  }
+  if (std::strcmp(name, "bsr_nt") == 0) {
+    h->bsr_nt = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "ell_order") == 0) {
+    h->ell_order = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "bench_what") == 0) {
+    if (value < 0.0 || value > 3.0) return sw_fail(h, "bench_what must be 0..3");
+    h->bench_what = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "bench_mode") == 0) {
+    if (value != 0.0 && value != 1.0 && value != 2.0) return sw_fail(h, "bench_mode must be 0, 1 or 2");
+    h->bench_mode = (int)value;
     return 0;
   }
   if (std::strcmp(name, "stencil_nt") == 0) {
@@ -1763,7 +1806,8 @@ static int deflate(sw_engine* h, const cplx* U, int kd, const int* srcrow, const
     {
       LaunchScope ls(h, T_DEFL);
       hipLaunchKernelGGL(swk::k_reduce_partials, dim3(kc, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
-                         h->partial, P, kc, nbp, cbuf + (size_t)k0 * nbp);
+                         h->partial, P, kc, nbp, cbuf + (size_t)k0 * nbp, (const cplx*)nullptr,
+                         (cplx*)nullptr);
       KLAUNCH_CHECK();
     }
   }
@@ -1927,12 +1971,30 @@ int sw_bench_dirac(sw_engine* h, int hid, int level, int nb, int reps, double* m
   }
   const bool prof = h->profiling;
   h->profiling = false;
-  for (int i = 0; i < 3; ++i) SWCHK(apply_op(h, lv, 0, a, nullptr, b, nbp));
+  const int bm = h->bench_mode;
+  const int what = h->bench_what;
+  Hier& H = h->hier[hid];
+  if ((what == 1 || what == 2) && level + 1 >= H.nlevels) return sw_fail(h, "no transfer at this level");
+  if (what == 1 || what == 2) SWCHK(ensure_level_ws(h, H.lv[level + 1], nbp));
+  if (what == 3) SWCHK(ensure_level_ws(h, H.lv[H.nlevels - 1], nbp));
+  cplx* c = lv.r;   // third buffer: the right-hand side of modes 1 / 2
+  if (bm != 0) HIPCHK(hipMemcpy(c, a, (size_t)lv.n * nbp * sizeof(cplx), hipMemcpyDeviceToDevice));
+  const cplx wgt = cplx{0.31, 0.07};
+  auto one = [&](int i) -> int {
+    if (what == 1) return launch_ell(h, lv.R, 0, a, nullptr, H.lv[level + 1].b, nbp, T_R);
+    if (what == 2) return launch_ell(h, lv.P, 0, H.lv[level + 1].b, nullptr, b, nbp, T_P);
+    if (what == 3) {
+      Level& ll = H.lv[H.nlevels - 1];
+      return apply_coarsest(h, H, (i & 1) ? ll.x : ll.b, (i & 1) ? ll.b : ll.x, nbp);
+    }
+    return apply_op(h, lv, bm, (i & 1) ? b : a, bm ? c : nullptr, (i & 1) ? a : b, nbp, wgt);
+  };
+  for (int i = 0; i < 3; ++i) SWCHK(one(i));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, h->stream));
-  for (int i = 0; i < reps; ++i) SWCHK(apply_op(h, lv, 0, (i & 1) ? b : a, nullptr, (i & 1) ? a : b, nbp));
+  for (int i = 0; i < reps; ++i) SWCHK(one(i));
   HIPCHK(hipEventRecord(e1, h->stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -375,15 +375,16 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step_lds(const cplx* __re
 template <int G, int MODE>
 __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
                                                   const cplx* __restrict__ vals, int K,
-                                                  int ngroups,
+                                                  int ngroups, const int* __restrict__ order,
                                                   const cplx* __restrict__ X,
                                                   const cplx* __restrict__ B,
                                                   cplx* __restrict__ Y, int nbp, cplx w) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int bx = xcd_remap(blockIdx.x, gridDim.x);   // contiguous row band per XCD (L2 reuse)
-  const int grp = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + wave);
-  if (grp >= ngroups) return;
+  const int slot = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + wave);
+  if (slot >= ngroups) return;
+  const int grp = order ? __builtin_amdgcn_readfirstlane(order[slot]) : slot;
   const size_t col = (size_t)blockIdx.y * 64 + lane;
   const int* c = cols + (size_t)grp * K;
   const cplx* v = vals + (size_t)grp * K * G;
@@ -434,13 +435,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 // ------------------------------------------------------------------------------------------
 typedef double sw_double4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int NT>
+template <int MODE, int NT, bool NTIO = false>
 __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ Ap,
                                                        const int* __restrict__ kcol, int KS,
                                                        int RT, const double* __restrict__ Xr,
                                                        const double* __restrict__ Br,
                                                        double* __restrict__ Yr, int ld, int nbp,
-                                                       cplx w) {
+                                                       cplx w, int map, int msub) {
   // the 4 waves of a workgroup take 4 consecutive row tiles and the SAME 64-probe chunk, so
   // the X rows they share (all of them for a dense operator, the common neighbours for a
   // block stencil) are served once from L2 and then from the CU's L1
@@ -448,10 +449,31 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   // XCD-aware: consecutive block ids are dealt round-robin over the 8 XCDs; remapping hands each
   // XCD one contiguous band of row tiles, so the X rows its tiles share (lattice neighbours of a
   // block stencil) are fetched into that XCD's L2 once instead of into all eight
-  const int bx = xcd_remap(blockIdx.x, gridDim.x);
+  // 1-D grid of RB x NC blocks (RB row blocks of 4 tiles, NC probe chunks); `map` orders them:
+  //   0: chunk-major, the row blocks of one chunk dealt to the XCDs in contiguous bands
+  //   1: XCD band of row blocks, the NC chunks of a row block adjacent in time (A tile read once)
+  //   2: as 1, in sub-bands of `msub` row blocks: chunk loop over a sub-band, then the next one
+  const int RB = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const int NC = gridDim.x / RB;
+  int bx, cy;
+  if (map == 0 || (RB & 7)) {
+    cy = blockIdx.x / RB;
+    bx = xcd_remap(blockIdx.x - cy * RB, RB);
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, RBx = RB >> 3;
+    if (map == 1 || (RBx % msub)) {
+      cy = j % NC;
+      bx = xcd * RBx + j / NC;
+    } else {
+      const int per = NC * msub;
+      const int sidx = j / per, rem = j - sidx * per;
+      cy = rem / msub;
+      bx = xcd * RBx + sidx * msub + (rem - cy * msub);
+    }
+  }
   const int rt = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (rt >= RT) return;
-  const int c0 = blockIdx.y * (16 * NT);            // first real column of this chunk
+  const int c0 = cy * (16 * NT);                    // first real column of this chunk
   const cplx* a = Ap + (size_t)rt * KS * 64 + lane;
   const int* kc = kcol + (size_t)rt * KS;           // wave-uniform -> scalar loads
   const double* b = Xr + (size_t)(lane >> 4) * ld + c0 + (lane & 15);
@@ -503,13 +525,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
       const double s = __shfl_xor(im[t][r], 1);
       double y = odd ? re[t][r] + s : re[t][r] - s;
       const size_t off = row * ld + c0 + t * 16 + c;
-      if (MODE == 1) y = Br[off] - y;
+      // B is read once, by exactly this lane: streamed past L2 (nt) when NTIO, so that the operator's
+      // values, which every probe chunk of this XCD's row band re-reads, stay resident there
+      // (hoisting these loads above the MFMA loop was measured 5 % SLOWER: register pressure)
+      if (MODE == 1) y = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
       if (MODE == 3) {
-        const double tt = Br[off] - y;
+        const double tt = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
         const double tp = __shfl_xor(tt, 1);
         y = Xr[off] + w.x * tt + (odd ? w.y * tp : -w.y * tp);
       }
-      Yr[off] = y;
+      if (NTIO) __builtin_nontemporal_store(y, &Yr[off]);
+      else Yr[off] = y;
     }
   }
 }
@@ -806,9 +832,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrList V, int K, const c
 // out[k*nbp + col] = sum_p partial[(p*K + k)*nbp + col]
 // grid = (K, nbp/64); the four waves of a block take p = wave, wave+4, ... with independent
 // loads in flight, then combine through LDS in a fixed order (deterministic).
+// optional second output (batched FGMRES on an UNNORMALISED basis, see k_fg_hess):
+//   coef[k*nbp + col] = svec[k*nbp + col].x^2 * out[k*nbp + col]
 __global__ __launch_bounds__(SW_BLOCK) void k_reduce_partials(const cplx* __restrict__ partial,
                                                               int P, int K, int nbp,
-                                                              cplx* __restrict__ out) {
+                                                              cplx* __restrict__ out,
+                                                              const cplx* __restrict__ svec,
+                                                              cplx* __restrict__ coef) {
   __shared__ cplx red[3][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k = blockIdx.x;
@@ -836,6 +866,10 @@ __global__ __launch_bounds__(SW_BLOCK) void k_reduce_partials(const cplx* __rest
     s = cadd(s, red[1][lane]);
     s = cadd(s, red[2][lane]);
     out[(size_t)k * nbp + col] = s;
+    if (svec) {
+      const double q = svec[(size_t)k * nbp + col].x;
+      coef[(size_t)k * nbp + col] = cmake(q * q * s.x, q * q * s.y);
+    }
   }
 }
 
@@ -904,24 +938,6 @@ __global__ __launch_bounds__(SW_BLOCK) void k_mr_update(const cplx* __restrict__
     cfma(rr, cmake(-al.x, -al.y), t);
     X[off] = x;
     R[off] = rr;
-  }
-}
-
-// dst[r] = s[col] * src[r]   (s real per probe, stored as the .x of a cplx array)
-__global__ __launch_bounds__(SW_BLOCK) void k_scale(const cplx* __restrict__ s,
-                                                    const cplx* __restrict__ src,
-                                                    cplx* __restrict__ dst, int n, int nbp,
-                                                    int rows_per_block) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t col = (size_t)blockIdx.y * 64 + lane;
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(n, r0 + rows_per_block);
-  const double f = s[col].x;
-#pragma unroll 2
-  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
-    const size_t off = (size_t)r * nbp + col;
-    const cplx v = src[off];
-    dst[off] = cmake(f * v.x, f * v.y);
   }
 }
 
@@ -1027,7 +1043,8 @@ struct FgScalars {
   cplx* y;        // [m][nbp]
   cplx* normb;    // [nbp] .x
   cplx* relres;   // [nbp] .x
-  cplx* scale;    // [nbp] .x  (1/beta or 1/h_{j+1,j})
+  cplx* svec;     // [(m+1)][nbp] .x: scale of basis vector k, v_k = svec_k * vtilde_k (0: frozen)
+  cplx* ys;       // [m][nbp] y_k * svec_k: coefficients of the update x += sum_k ys_k ztilde_k
   int* iters;     // [nbp] iteration at which the probe first met tol (-1: not yet)
   int* notconv;   // [1] number of probes still above tol
   int m;
@@ -1045,22 +1062,35 @@ __global__ void k_fg_begin(FgScalars s, const cplx* __restrict__ d, int first_cy
     s.relres[col] = cmake(beta > 0.0 ? 1.0 : 0.0, 0.0);
   }
   s.g[col] = cmake(beta, 0.0);
-  s.scale[col] = cmake(beta > 0.0 ? 1.0 / beta : 0.0, 0.0);
+  s.svec[col] = cmake(beta > 0.0 ? 1.0 / beta : 0.0, 0.0);   // vtilde_0 = r itself
 }
 
-// column j of the Hessenberg matrix: h = h1 + h2 (two Gram-Schmidt passes), h_{j+1,j} = sqrt(nrm2)
+// Column j of the Hessenberg matrix.  The Krylov basis is kept UNNORMALISED in memory: the stored
+// vtilde_k and the true orthonormal v_k differ by a per-probe scale, v_k = svec_k vtilde_k (vtilde_0
+// is the residual itself, vtilde_{k+1} the orthogonalised A M vtilde_k as multiaxpy leaves it), so no
+// pass over the vectors is spent on normalisation; the multigrid cycle and A are linear, so
+// ztilde_k = M vtilde_k and z_k = svec_k ztilde_k.  With the raw dots d_k = vtilde_k^H (A ztilde_j)
+// (d1 + d2: two Gram-Schmidt passes) and nrm2 = |vtilde_{j+1}|^2:
+//   h_{k,j} = svec_k svec_j d_k,   h_{j+1,j} = svec_j sqrt(nrm2),   svec_{j+1} = 1/sqrt(nrm2)
+// (the orthogonalisation coefficients svec_k^2 d_k come from k_reduce_partials).
 __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
                           const cplx* __restrict__ h2, const cplx* __restrict__ nrm2, double tol,
                           int iter_base) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= s.nbp) return;
   const int m = s.m, nbp = s.nbp;
-  const double hn = sqrt(fmax(nrm2[col].x, 0.0));
+  const double sj = s.svec[(size_t)j * nbp + col].x;
+  const double wn = sqrt(fmax(nrm2[col].x, 0.0));
+  const double hn = sj * wn;
   // apply the previous rotations
+  const double s0 = s.svec[col].x * sj;
   cplx hk = cadd(h1[col], h2[col]);
+  hk = cmake(s0 * hk.x, s0 * hk.y);
   double hcol2 = hk.x * hk.x + hk.y * hk.y;      // |h_{0..j,j}|^2 before the rotations
   for (int k = 0; k < j; ++k) {
-    const cplx hk1 = cadd(h1[(size_t)(k + 1) * nbp + col], h2[(size_t)(k + 1) * nbp + col]);
+    const double sk1 = s.svec[(size_t)(k + 1) * nbp + col].x * sj;
+    cplx hk1 = cadd(h1[(size_t)(k + 1) * nbp + col], h2[(size_t)(k + 1) * nbp + col]);
+    hk1 = cmake(sk1 * hk1.x, sk1 * hk1.y);
     hcol2 = fma(hk1.x, hk1.x, fma(hk1.y, hk1.y, hcol2));
     const double c = s.cs[(size_t)k * nbp + col].x;
     const cplx sn = s.sn[(size_t)k * nbp + col];
@@ -1112,7 +1142,7 @@ __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
   // later Hessenberg column of this probe exactly zero, and k_fg_solve gives y = 0 for them.
   const bool frozen = (s.iters[col] >= 0 && rr < 1.0e-2 * tol) ||
                       (hn * hn <= 1.0e-28 * (hcol2 + hn * hn));
-  s.scale[col] = cmake((hn > 0.0 && !frozen) ? 1.0 / hn : 0.0, 0.0);
+  s.svec[(size_t)(j + 1) * nbp + col] = cmake((hn > 0.0 && !frozen) ? 1.0 / wn : 0.0, 0.0);
 }
 
 // true-residual check after a solve: d[col].x = ||b - A x||^2; probes above tol are counted and
@@ -1146,6 +1176,8 @@ __global__ void k_fg_solve(FgScalars s, int k) {
     cplx yi = cmake(0.0, 0.0);
     if (dd > 0.0) yi = cmake((t.x * hii.x + t.y * hii.y) / dd, (t.y * hii.x - t.x * hii.y) / dd);
     s.y[(size_t)i * nbp + col] = yi;
+    const double si = s.svec[(size_t)i * nbp + col].x;
+    s.ys[(size_t)i * nbp + col] = cmake(si * yi.x, si * yi.y);
   }
 }
 

@@ -20,6 +20,12 @@ struct EllHost {
   int K = 0, G = 1, ngroups = 0;
   std::vector<int> cols;
   std::vector<std::complex<double>> vals;
+  // optional processing order of the row groups (empty: natural).  For tall operators
+  // (prolongators) whose consecutive row groups do NOT share columns -- level 0 rows are in
+  // even-odd lattice order, an aggregate's rows are spread over both parity halves -- the groups
+  // are visited sorted by their first column, so the waves of a workgroup and the row band of an
+  // XCD read the same coarse rows (each fetched into ONE L2, once).
+  std::vector<int> order;
 };
 
 struct BsrHost {
@@ -33,7 +39,7 @@ struct BsrHost {
 inline int ell_pack(EllHost& out, std::string& err, int nrows, int ncols, const int64_t* indptr,
                     const int32_t* indices, const std::complex<double>* data,
                     const std::vector<int>& rows_int, const std::vector<int>& colmap,
-                    int forceG = 0) {
+                    int forceG = 0, bool sort_by_column = false) {
   char buf[160];
   if (nrows <= 0 || ncols <= 0) {
     err = "build_ell: empty operator";
@@ -124,6 +130,17 @@ inline int ell_pack(EllHost& out, std::string& err, int nrows, int ncols, const 
         out.vals[((size_t)gi * K + k) * G + g] += data[q];
       }
     }
+  }
+  out.order.clear();
+  if (sort_by_column) {
+    out.order.resize(ng);
+    for (int gi = 0; gi < ng; ++gi) out.order[gi] = gi;
+    std::stable_sort(out.order.begin(), out.order.end(), [&](int a, int b) {
+      return out.cols[(size_t)a * K] < out.cols[(size_t)b * K];
+    });
+    bool identity = true;
+    for (int gi = 0; gi < ng; ++gi) identity = identity && out.order[gi] == gi;
+    if (identity) out.order.clear();
   }
   return 0;
 }

@@ -92,6 +92,12 @@ struct Level {
   // per-level cycle workspace, [n][nbp]
   int ws_nbp = 0;
   cplx *b = nullptr, *x = nullptr, *r = nullptr, *t = nullptr;
+  // reference-faithful smoother: gm_cycles restart cycles of unpreconditioned GMRES(gm_m) from a
+  // zero guess, the engine's counterpart of lgmres(maxiter=smooth_iters) with inner_m = 30
+  // (multigrid.py:393-394,438-439).  gm_m == 0: off
+  int gm_m = 0, gm_cycles = 0;
+  cplx *g1 = nullptr, *g2 = nullptr;
+  KrylovWS gws;   // smoother workspace
   KrylovWS kws;   // K-cycle workspace
   KrylovWS sws;   // outer-solve workspace
 };
@@ -671,7 +677,8 @@ static int ensure_krylov(sw_engine* h, KrylovWS& w, int m, int n, int nbp, bool 
 // the multigrid cycle (MG.one_mg_step, multigrid.py:369-447) with MR(nu) smoothing
 // ---------------------------------------------------------------------------------------------
 static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, double tol, int maxiter,
-                  int m, bool outer, KrylovWS& ws, int nbp, int* iters_total);
+                  int m, bool outer, KrylovWS& ws, int nbp, int* iters_total,
+                  bool use_precond = true);
 
 // nu MR steps on (X, R) with R = B - A X maintained
 static int mr_smooth(sw_engine* h, Level& lv, cplx* X, cplx* R, int nu, int nbp) {
@@ -766,7 +773,54 @@ static int rich_steps(sw_engine* h, Level& lv, const cplx* Bin, cplx* cur, cplx*
 
 static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp);
 
+static int vec_add(sw_engine* h, const cplx* a, const cplx* b, cplx* dst, int n, int nbp) {
+  LaunchScope ls(h, T_AXPY);
+  hipLaunchKernelGGL(swk::k_add, dim3(2048), dim3(SW_BLOCK), 0, h->stream, a, b, dst,
+                     (size_t)n * nbp);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+// E = gm_cycles x GMRES(gm_m) applied to A_l e = R from a zero guess (unpreconditioned)
+static int gmres_smooth(sw_engine* h, Hier& H, int l, const cplx* R, cplx* E, int nbp) {
+  Level& lv = H.lv[l];
+  const int m = lv.gm_m;
+  SWCHK(ensure_krylov(h, lv.gws, m, lv.n, nbp, false));
+  SWCHK(fgmres(h, H, l, R, E, 0.0, m, m, false, lv.gws, nbp, nullptr, false));
+  for (int c = 1; c < lv.gm_cycles; ++c) {
+    SWCHK(apply_op(h, lv, 1, E, R, lv.g1, nbp));                       // g1 = R - A E
+    SWCHK(fgmres(h, H, l, lv.g1, lv.g2, 0.0, m, m, false, lv.gws, nbp, nullptr, false));
+    SWCHK(vec_add(h, E, lv.g2, E, lv.n, nbp));
+  }
+  return 0;
+}
+
+static int vcycle(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp);
+
+// MG.one_mg_step as written (multigrid.py:369-447): smooth, residual, restrict, recurse, prolong,
+// residual, smooth -- with the GMRES(m) x cycles smoother above in place of lgmres(maxiter=2)
+static int vcycle_gmres(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
+  Level& lv = H.lv[l];
+  Level& lc = H.lv[l + 1];
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  SWCHK(ensure_level_ws(h, lc, nbp));
+  if (!lv.P.set || !lv.R.set) return sw_fail(h, "transfer operators of level %d not set", l);
+  if (!lv.g1 || lv.gws.nbp != nbp) {
+    SWCHK(dev_realloc(h, &lv.g1, (size_t)lv.n * nbp));
+    SWCHK(dev_realloc(h, &lv.g2, (size_t)lv.n * nbp));
+  }
+  SWCHK(gmres_smooth(h, H, l, Bin, Xout, nbp));                         // :388-399  (x = 0 + e)
+  SWCHK(apply_op(h, lv, 1, Xout, Bin, lv.r, nbp));                      // :402
+  SWCHK(launch_ell(h, lv.R, 0, lv.r, nullptr, lc.b, nbp, T_R));         // :406
+  SWCHK(vcycle(h, H, l + 1, lc.b, lc.x, nbp));                          // :413-416 at the coarsest
+  SWCHK(launch_ell(h, lv.P, 2, lc.x, Xout, Xout, nbp, T_P));            // :429
+  SWCHK(apply_op(h, lv, 1, Xout, Bin, lv.r, nbp));                      // :433
+  SWCHK(gmres_smooth(h, H, l, lv.r, lv.t, nbp));                        // :438
+  return vec_add(h, Xout, lv.t, Xout, lv.n, nbp);                       // :444
+}
+
 static int vcycle(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
+  if (l < H.nlevels - 1 && H.lv[l].gm_m > 0) return vcycle_gmres(h, H, l, Bin, Xout, nbp);
   if (l < H.nlevels - 1 && H.lv[l].rich) return vcycle_rich(h, H, l, Bin, Xout, nbp);
   const int last = H.nlevels - 1;
   if (l == last) {
@@ -850,13 +904,13 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
 //  outer == false: exactly `maxiter` (= m) steps from a zero guess, no host synchronisation
 // ---------------------------------------------------------------------------------------------
 static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, double tol, int maxiter,
-                  int m, bool outer, KrylovWS& ws, int nbp, int* iters_total) {
+                  int m, bool outer, KrylovWS& ws, int nbp, int* iters_total, bool use_precond) {
   Level& lv = H.lv[level];
   const int hid_idx = (int)(&H - &h->hier[0]);
   const int check_from = (outer && h->lazy_sync) ? std::max(0, h->sync_hint[hid_idx][level] - 2) : 0;
   const int n = lv.n;
   const size_t vec = (size_t)n * nbp;
-  const bool precond = (level < H.nlevels - 1);
+  const bool precond = use_precond && (level < H.nlevels - 1);
   const int tb = 256, tg = (nbp + tb - 1) / tb;
   int done = 0;
   bool first = true;
@@ -1092,6 +1146,8 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(dev_free(h, lv.t));
     SWCHK(free_krylov(h, lv.kws));
     SWCHK(free_krylov(h, lv.sws));
+    SWCHK(free_krylov(h, lv.gws));
+    SWCHK(dev_free(h, lv.g1)); SWCHK(dev_free(h, lv.g2));
     lv = Level();
   }
   SWCHK(free_op(h, H.cinv));
@@ -1280,6 +1336,16 @@ int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w
   for (int i = 0; i < n_pre; ++i) lv.w_pre.emplace_back(w_pre[2 * i], w_pre[2 * i + 1]);
   for (int i = 0; i < n_post; ++i) lv.w_post.emplace_back(w_post[2 * i], w_post[2 * i + 1]);
   lv.rich = (n_pre + n_post) > 0;
+  return 0;
+}
+
+int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (m < 0 || m > SW_MAXM || (m > 0 && cycles < 1) || cycles > 16)
+    return sw_fail(h, "sw_set_gmres_smoother: need 0 <= m <= %d and 1 <= cycles <= 16", SW_MAXM);
+  Level& lv = h->hier[hid].lv[level];
+  lv.gm_m = m;
+  lv.gm_cycles = m > 0 ? cycles : 0;
   return 0;
 }
 
@@ -1860,6 +1926,23 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
     SWCHK(dot_into(h, h->pb_x0, h->pb_z, n, nbp, h->pb_est));   // e = x^H z   utils.py:249
     SWCHK(stream_sync(h));
     SWCHK(record_iters(h, &h->hier[fine_hid].lv[0].sws, total, h->last_iters_f, nb));
+    h->last_iters_c.assign(nb, 0);
+    return 0;
+  }
+  if (mode == SW_MODE_LEVEL) {
+    // e = x0^H A_l^-1 (Bblock_perm_l Pperm_l^T) x0: the plain Hutchinson estimator of one level's
+    // trace term (stochastic form of the coarsest-level term, stoch_trace.py:428-437)
+    const cplx* xdef = h->pb_x0;
+    if (h->rhsmap[level].set) {
+      SWCHK(launch_ell(h, h->rhsmap[level], 0, xdef, nullptr, h->pb_rhs, nbp, T_OTHER));
+      xdef = h->pb_rhs;
+    }
+    int total = 0;
+    SWCHK(solve_dev(h, fine_hid, level, xdef, h->pb_z, tol, maxiter, nbp, &total));
+    SWCHK(dot_into(h, h->pb_x0, h->pb_z, n, nbp, h->pb_est));
+    SWCHK(stream_sync(h));
+    if (level == H0.nlevels - 1 && H0.nlevels > 1) h->last_iters_f.assign(nb, 1);
+    else SWCHK(record_iters(h, &h->hier[fine_hid].lv[level].sws, total, h->last_iters_f, nb));
     h->last_iters_c.assign(nb, 0);
     return 0;
   }

@@ -949,6 +949,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_cscale(cplx w, const cplx* __restr
   for (; i < count; i += stride) dst[i] = cmul(w, src[i]);
 }
 
+// dst = a + b
+__global__ __launch_bounds__(SW_BLOCK) void k_add(const cplx* __restrict__ a, const cplx* __restrict__ b,
+                                                  cplx* __restrict__ dst, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) dst[i] = cadd(a[i], b[i]);
+}
+
 // dst[r] = src[srcrow[r]]  (row gather: the Pperm^T index shift in the internal row order)
 __global__ __launch_bounds__(SW_BLOCK) void k_gather_rows(const int* __restrict__ srcrow,
                                                           const cplx* __restrict__ src,

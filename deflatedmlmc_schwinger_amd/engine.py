@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libschwinger_hip.so")
 MODE_HUTCHINSON = 0
 MODE_MLMC = 1
 MODE_MLMC_SKIP = 2
+MODE_LEVEL = 3
 PROBES_Z2 = 1
 PROBES_Z4 = 2
 PROBE_KINDS = {"z2": PROBES_Z2, "z4": PROBES_Z4}
@@ -65,6 +66,7 @@ def load_library():
     sig("sw_set_coarsest_inv", i32, vp, i32, i32, vp)
     sig("sw_set_cycle", i32, vp, i32, i32, i32, i32, i32)
     sig("sw_set_smoother", i32, vp, i32, i32, i32, vp, i32, vp)
+    sig("sw_set_gmres_smoother", i32, vp, i32, i32, i32, i32)
     sig("sw_hier_end", i32, vp, i32)
     sig("sw_set_deflation", i32, vp, i32, vp)
     sig("sw_set_level_deflation", i32, vp, i32, i32, vp)
@@ -113,7 +115,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_set_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
+    "sw_set_smoother", "sw_set_gmres_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -224,6 +226,10 @@ class Engine:
         self._chk(self._lib.sw_set_smoother(self._h, hid, level, wp.size,
                                             _ptr(wp) if wp.size else None, wq.size,
                                             _ptr(wq) if wq.size else None), "sw_set_smoother")
+
+    def set_gmres_smoother(self, hid, level, m, cycles):
+        self._chk(self._lib.sw_set_gmres_smoother(self._h, hid, level, int(m), int(cycles)),
+                  "sw_set_gmres_smoother")
 
     def hier_end(self, hid):
         self._chk(self._lib.sw_hier_end(self._h, hid), "sw_hier_end")

@@ -160,6 +160,9 @@ class MG:
                 nu_post = int(params.get("ref_cycle_post", 4)) if params else 4
                 eng.set_cycle(REF_HID, i, 0, nu_post,
                               int(params.get("ref_cycle_k", 0)) if params else 0)
+                if params and params.get("ref_smoother") == "gmres30x2":
+                    # reference-faithful cycle: lgmres(maxiter=smooth_iters), inner_m = 30
+                    eng.set_gmres_smoother(REF_HID, i, 30, self.smooth_iters)
                 if params and params.get("ref_smoother") == "richardson":
                     # fixed polynomial instead of MR(nu) on the reference hierarchy's levels
                     if ("ref", i, nu_post) not in self._ref_weights:

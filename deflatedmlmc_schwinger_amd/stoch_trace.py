@@ -336,6 +336,28 @@ def mlmc(A, params):
             crst_mat = levels[last].Pperm.transpose().conjugate() * (crst_mat * levels[last].Bblock_perm)
         output_params['results'][last]['ests_avg'] = np.trace(crst_mat)
         output_params['results'][last]['ests_dev'] = 0
+    elif params.get('stochastic_coarsest'):
+        # build-only option (the reference raises here): the coarsest term tr(Pperm^H A_c^-1 Bblock)
+        # by plain Hutchinson probes on the coarsest level, with the tolerance share of the last
+        # difference level
+        n_c = levels[last].A.shape[0]
+        if nr_levels == 3:
+            tol_fctr = sqrt(1.0 - frac0) if skip_level else sqrt(frac1)
+        elif skip_level:
+            tol_fctr = sqrt(1.0 - frac0) / sqrt(nr_levels - 3)
+        else:
+            tol_fctr = sqrt(1.0 - frac0 - frac1) / sqrt(nr_levels - 3)
+        level_trace_tol = abs(params['tol'] * rough_trace * tol_fctr)
+        source = DeviceProbes(mg_solver, params, "level", last, params.get('probe_type', 'z2'))
+        loop = run_probe_loop(source, n_c, level_trace_tol, params['max_nr_ests'], batch,
+                              probe_type=params.get('probe_type', 'z2'))
+        res = output_params['results'][last]
+        res['function_iters'] += int(np.sum(loop["iters_fine"]))
+        res['nr_ests'] += loop["index"]
+        res['ests_avg'] = loop["avg"]
+        res['ests_dev'] = loop["dev"]
+        res['ests'] = loop["ests"]
+        res['level_tol'] = level_trace_tol
     else:
         raise Exception("Stochastic coarsest-level computation is disabled at the moment.")
 

@@ -7,7 +7,7 @@ import numpy as np
 from scipy.sparse.linalg import eigsh
 
 from . import dist as _dist
-from .engine import MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP, EngineError
+from .engine import MODE_HUTCHINSON, MODE_LEVEL, MODE_MLMC, MODE_MLMC_SKIP, EngineError
 
 
 # ----------------------------------------------------------------------------------------
@@ -251,12 +251,7 @@ def probe_batch(mg_solver, params, method, probes, level=0):
     tol = params['function_params']['tol']
     n = mg_solver.ml.levels[level].A.shape[0]
     maxiter = n if n < 1000 else 1000
-    if method == "hutchinson":
-        mode = MODE_HUTCHINSON
-    elif method == "mlmc":
-        mode = MODE_MLMC_SKIP if (mg_solver.skip_level and level == 0) else MODE_MLMC
-    else:
-        raise Exception("unknown method")
+    mode = _probe_mode(mg_solver, method, level)
     probes = np.asarray(probes)
     nb = probes.shape[0]
     if len(engs) == 1 or nb < 2 * 64:
@@ -277,6 +272,8 @@ def _probe_mode(mg_solver, method, level):
         return MODE_HUTCHINSON
     if method == "mlmc":
         return MODE_MLMC_SKIP if (mg_solver.skip_level and level == 0) else MODE_MLMC
+    if method == "level":
+        return MODE_LEVEL
     raise Exception("unknown method")
 
 

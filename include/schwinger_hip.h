@@ -70,6 +70,13 @@ int sw_set_cycle(sw_engine* h, int hid, int level, int nu_pre, int nu_post, int 
  * n_pre = n_post = 0 returns to MR(nu) of sw_set_cycle. */
 int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w_pre, int n_post,
                     const double* w_post);
+/* Reference-faithful cycle at `level` ("function_iters / total_complexity in both
+ * modes"): MG.one_mg_step exactly as multigrid.py:369-447 lays it out -- smooth, residual,
+ * restrict, recurse, prolong, residual, smooth -- with `cycles` restart cycles of unpreconditioned
+ * GMRES(m) from a zero guess as the smoother, the counterpart of
+ * lgmres(A_l, r, tol=1e-20, maxiter=smooth_iters=2) with SciPy's inner_m = 30 (SURVEY F5;
+ * LGMRES's single augmentation vector in the second cycle is not reproduced).  m = 0 switches back. */
+int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles);
 /* Mark the hierarchy complete (allocates level workspaces lazily). */
 int sw_hier_end(sw_engine* h, int hid);
 
@@ -114,6 +121,10 @@ int sw_solve(sw_engine* h, int hid, int level0, int nb, const double* B, double*
 #define SW_MODE_HUTCHINSON 0   /* utils.py:210-250 */
 #define SW_MODE_MLMC 1         /* utils.py:252-361 */
 #define SW_MODE_MLMC_SKIP 2    /* utils.py:252-361 with mg_solver.skip_level and i == 0 */
+#define SW_MODE_LEVEL 3        /* e_k = x^H A_l^-1 C_l x: one level's own trace term, estimated
+                                  stochastically (build-only; the reference computes the coarsest
+                                  term directly and raises for the stochastic form,
+                                  stoch_trace.py:428-437) */
 /* One batch of probes x_k in {-1,+1}^n (int8, nb*n, reference ordering) at `level`
  * (build-only extension: entries +-2 encode +-i, i.e. Z4 probes {1,i,-1,-i}):
  *   HUTCHINSON: e_k = x^H A^-1 Pperm^T (x - U U^H x)

@@ -13,7 +13,8 @@ import scipy.sparse as sp
 pytestmark = pytest.mark.gpu
 
 from deflatedmlmc_schwinger_amd import gateway, matrix, utils  # noqa: E402
-from deflatedmlmc_schwinger_amd.engine import (MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP)  # noqa: E402
+from deflatedmlmc_schwinger_amd.engine import (MODE_HUTCHINSON, MODE_LEVEL, MODE_MLMC,  # noqa: E402
+                                               MODE_MLMC_SKIP)
 from deflatedmlmc_schwinger_amd.multigrid import MG, REF_HID, SOLVER_HID  # noqa: E402
 from oracle import engine_model as em  # noqa: E402
 from oracle import ref_path as rp  # noqa: E402
@@ -680,3 +681,77 @@ def test_z4_probes_build_only_option(p16):
         assert abs(ests[k] - ref) / abs(ref) < 1e-10
     exact = 265.8581064657958
     assert abs(ests.mean() - exact) < 4.0 * ests.std() / np.sqrt(32)
+
+
+def test_stochastic_coarsest_level_build_only_option(p16, p128, capsys):
+    """the coarsest-level term estimated stochastically (the reference raises
+    "Stochastic coarsest-level computation is disabled", stoch_trace.py:436-437; here it is a flagged
+    build-only option).  Per probe e = x^H A_c^-1 (Bblock_perm Pperm^T) x against NumPy, the mean
+    against the direct value np.trace(Pperm^H A_c^-1 Bblock_perm) of stoch_trace.py:431-435."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    for p in (p16, p128):
+        last = len(p.levels) - 1
+        cinv = np.asarray(p.mg.coarsest_inv)
+        n = cinv.shape[0]
+        np.random.seed(77)
+        probes = utils.draw_probes(40, n)
+        ests, _, _ = p.eng.hutch_batch(MODE_LEVEL, last, probes, 1e-12, 1000)
+        lev = p.levels[last]
+        for k in range(40):
+            x = probes[k].astype(np.complex128)
+            rhs = x if isinstance(lev.Pperm, int) else lev.Bblock_perm @ (lev.Pperm.transpose() @ x)
+            ref = np.vdot(x, cinv @ rhs)
+            assert abs(ests[k] - ref) < 1e-11 * max(1.0, abs(ref))
+    # whole flow on 16^2: default raises like the reference, the flag runs the estimator
+    params = gateway.set_params('schwinger16')
+    params.update({'function_tol': 1e-12, 'nr_deflat_vctrs': 8, 'mlmc_deflat_vctrs': [0, 0],
+                   'trace_tol': 2.0e-2, 'coarsest_level_directly': False})
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    tp['batch'] = 64
+    with pytest.raises(Exception, match="Stochastic coarsest-level computation is disabled"):
+        stoch_trace.mlmc(A, tp)
+    capsys.readouterr()
+    tp['stochastic_coarsest'] = True
+    res = stoch_trace.mlmc(A, tp)
+    capsys.readouterr()
+    exact = 265.8581064657958
+    last = res['nr_levels'] - 1
+    assert res['results'][last]['nr_ests'] >= 5
+    err2 = sum(res['results'][i]['ests_dev'] ** 2 / (res['results'][i]['nr_ests'] + 1)
+               for i in (0, last))
+    assert abs(res['trace'] - exact) < 4.0 * np.sqrt(err2) + 1e-6 * exact, (res['trace'], np.sqrt(err2))
+
+
+def test_reference_faithful_cycle_reports_reference_iteration_counts():
+    """with ref_smoother="gmres30x2" level-0 solves are preconditioned by
+    the REFERENCE hierarchy and MG.one_mg_step's own cycle (multigrid.py:369-447) with 2 x GMRES(30)
+    in place of lgmres(maxiter=2), so `function_iters` is the reference's count.  Checked against the
+    oracle's restatement (SciPy lgmres smoother + flexible GMRES): same outer iteration count up to
+    the one LGMRES augmentation vector this mode leaves out, same solution."""
+    for name, nprobe in (('schwinger16', 4), ('schwinger128', 1)):
+        params = gateway.set_params(name)
+        params['function_tol'] = 1e-12
+        params['use_solver_hierarchy'] = False
+        params['ref_smoother'] = 'gmres30x2'
+        params['solver_restart'] = 32
+        A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+        tp = utils.trace_params_from_params(params, "hutchinson")
+        mg = MG(A)
+        mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+                 acc_eigvs=tp['accuracy_mg_eigvs'], sys_type='schwinger', params=tp)
+        omg = rp.OracleMG(A)
+        omg.setup(tp['dof'], tp['aggrs'], tp['max_nr_levels'], tp['accuracy_mg_eigvs'], tp,
+                  testvectors=mg.testvectors)
+        np.random.seed(123456)
+        B = utils.probes_as_complex(utils.draw_probes(nprobe, A.shape[0]))
+        X, its, relres = mg.solve_batch(0, B, 1e-12)
+        X, its = np.atleast_2d(X), np.atleast_1d(its)
+        for k in range(nprobe):
+            omg.level_nr = 0
+            omg.solve(A, B[k], 1e-12)
+            assert abs(int(its[k]) - int(omg.num_iters)) <= 2, (name, k, its[k], omg.num_iters)
+            assert _relerr(X[k], omg.x) < 1e-9
+        if name == 'schwinger128':
+            assert 10 <= int(its[0]) <= 16          # SURVEY F6: 13 outer iterations per plain probe
+        mg.engine.close()

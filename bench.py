@@ -307,7 +307,7 @@ def run(args):
         }
         peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (MFMA_F64_PEAK_TFLOPS, "TFLOP/s", 1e12)}
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "stencil_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "kernel_pmc.json")
         if synthetic:
             # several coarse levels share the MFMA operator kernel and the PMC figures were taken
             # on schwinger128: report the stencil and the dense kernel only, without traffic

@@ -369,8 +369,9 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
                       int nbp, int cat, cplx w) {
   const int RT = op.nrows / 16;
   const int NT = h->mfma_tiles;   // MFMA column tiles per wave (8 probes each)
-  dim3 grid(((RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK) * ((2 * nbp) / (16 * NT)));
   const int bmap = (cat == T_COARSEST) ? h->dense_map : h->bsr_map, msub = h->bsr_sub;
+  const int RBn = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, NCn = (2 * nbp) / (16 * NT);
+  dim3 grid = (bmap == 0) ? dim3(RBn, NCn) : dim3(RBn * NCn);
   LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE : (cat == T_MVM ? T_MFMA_OP : cat));
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
@@ -1390,7 +1391,7 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
       if (v < 1) return sw_fail(h, "bsr_sub must be >= 1");
       h->bsr_sub = v;
     } else {
-      if (v < 0 || v > 2) return sw_fail(h, "%s must be 0, 1 or 2", name);
+      if (v < 0 || v > 3) return sw_fail(h, "%s must be 0..3", name);
       (name[0] == 'd' ? h->dense_map : h->bsr_map) = v;
     }
     return 0;

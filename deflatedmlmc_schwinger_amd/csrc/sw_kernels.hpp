@@ -454,9 +454,12 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   //   1: XCD band of row blocks, the NC chunks of a row block adjacent in time (A tile read once)
   //   2: as 1, in sub-bands of `msub` row blocks: chunk loop over a sub-band, then the next one
   const int RB = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const int NC = gridDim.x / RB;
+  const int NC = (gridDim.y > 1) ? gridDim.y : gridDim.x / RB;
   int bx, cy;
-  if (map == 0 || (RB & 7)) {
+  if (gridDim.y > 1) {            // map 0 is launched as a 2-D grid (RB, NC)
+    cy = blockIdx.y;
+    bx = xcd_remap(blockIdx.x, RB);
+  } else if (map == 0 || map == 3 || (RB & 7)) {
     cy = blockIdx.x / RB;
     bx = xcd_remap(blockIdx.x - cy * RB, RB);
   } else {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: bench line, rocprofv3 kernel stats, and separate PMC passes (HBM traffic).
 set -e
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -44,7 +44,8 @@ def main(out):
     if pmc:
         lines.append("")
         lines.append("PMC passes (separate runs): per-launch averages; FETCH_SIZE/WRITE_SIZE are in KiB;")
-        lines.append("FETCH_SIZE is doubled for 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM)")
+        lines.append("FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md, HBM; the")
+        lines.append("factor 2 was re-measured for this engine's three read shapes, profiles/r02_pmc_calibration.txt)")
         names = sorted(set(list(pmc.get("FETCH_SIZE", {})) + list(pmc.get("WRITE_SIZE", {}))))
         lines.append("%-72s %12s %12s %12s" % ("kernel", "fetch_MB(x2)", "write_MB", "hbm_MB"))
         for k in names:
@@ -53,17 +54,24 @@ def main(out):
             fmb = 2.0 * f[1] / f[0] * 1024 / 1e6 if f else float("nan")
             wmb = w[1] / w[0] * 1024 / 1e6 if w else float("nan")
             lines.append("%-72s %12.2f %12.2f %12.2f" % (k, fmb, wmb, fmb + wmb))
-            for tag in ("k_stencil<0>", "k_stencil<1>", "k_stencil<2>"):
-                if tag[:-1] + "," in k or tag in k:
+            tags = {"k_stencil<0,": "k_stencil<0>", "k_stencil<1,": "k_stencil<1>",
+                    "k_stencil<2,": "k_stencil<2>",
+                    "k_bsr_mfma<0, 4, false>": "k_bsr_mfma(dense coarsest)",
+                    "k_bsr_mfma<3, 4, true>": "k_bsr_mfma(level-1 operator)",
+                    "k_bsr_mfma<3, 4, false>": "k_bsr_mfma(level-1 operator)"}
+            for pat, tag in tags.items():
+                if pat in k.replace("k_stencil<0, ", "k_stencil<0,").replace(
+                        "k_stencil<1, ", "k_stencil<1,").replace("k_stencil<2, ", "k_stencil<2,"):
                     summary[tag] = {"hbm_bytes_per_launch": (fmb + wmb) * 1e6,
                                     "fetch_bytes_per_launch_corrected": fmb * 1e6,
                                     "write_bytes_per_launch": wmb * 1e6}
     text = "\n".join(lines)
     open(os.path.join(out, "summary.txt"), "w").write(text + "\n")
     if summary:
-        summary["note"] = ("k_stencil<0> averages over all launches of one bench step; FETCH_SIZE "
-                           "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)")
-        json.dump(summary, open(os.path.join(out, "stencil_pmc.json"), "w"), indent=1)
+        summary["note"] = ("per-launch averages over one bench step (one stream); FETCH_SIZE doubled per "
+                           "MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B; factor re-measured "
+                           "for 16-B, 8-B and segmented 8-B reads in profiles/r02_pmc_calibration.txt)")
+        json.dump(summary, open(os.path.join(out, "kernel_pmc.json"), "w"), indent=1)
     print(text)
 
 

@@ -149,8 +149,10 @@ def run(args):
         depth = [[4, 8], [4, 8], [4, 8]] if Ls >= 1024 else ([[4, 8], [4, 8], [2, 8]] if Ls >= 512
                                                               else [[4, 8], [4, 8]])
         cyc = [[0, 7, 3]] * (len(depth) - 1) + [[0, 7, 0]]
-        scfg = {"coarsening": depth, "cycle": cyc, "restart": 8, "setup": "adaptive",
-                "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 100}
+        # GPU-side setup: inverse iteration, per-aggregate QR, P/R and R A P on the device
+        scfg = {"coarsening": depth, "cycle": cyc, "restart": 8,
+                "setup": os.environ.get("SW_SYNTH_SETUP", "device"),
+                "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1}
         if args.cfg:
             scfg = json.loads(args.cfg)
         mg = MG((Ls, -0.05, U1s, U2s))

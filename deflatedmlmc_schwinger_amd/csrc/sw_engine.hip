@@ -6,6 +6,8 @@
 #include "sw_kernels.hpp"
 #include "sw_pack.hpp"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -98,6 +100,8 @@ struct Level {
   int gm_m = 0, gm_cycles = 0;
   cplx *g1 = nullptr, *g2 = nullptr;
   KrylovWS gws;   // smoother workspace
+  // GPU-side setup: test vectors of this level, [n][64] (column = test vector), and a swap buffer
+  cplx *tv = nullptr, *tv2 = nullptr;
   KrylovWS kws;   // K-cycle workspace
   KrylovWS sws;   // outer-solve workspace
 };
@@ -407,6 +411,9 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   if (op.bsr_KS > 0 && (mode == 0 || mode == 1 || mode == 3) && h->use_mfma &&
       (cat == T_COARSEST || h->mfma_ops))
     return launch_bsr(h, op, mode, X, B, Y, nbp, cat, w);
+  if (!op.cols || !op.vals)
+    return sw_fail(h, "operator exists in MFMA block-row form only (built on the device): it needs "
+                      "use_mfma = mfma_ops = 1");
   dim3 grid((op.ngroups + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
   LaunchScope ls(h, cat);
 #define ELL_CASE(GG)                                                                            \
@@ -1149,6 +1156,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(free_krylov(h, lv.sws));
     SWCHK(free_krylov(h, lv.gws));
     SWCHK(dev_free(h, lv.g1)); SWCHK(dev_free(h, lv.g2));
+    SWCHK(dev_free(h, lv.tv)); SWCHK(dev_free(h, lv.tv2));
     lv = Level();
   }
   SWCHK(free_op(h, H.cinv));
@@ -1337,6 +1345,290 @@ int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w
   for (int i = 0; i < n_pre; ++i) lv.w_pre.emplace_back(w_pre[2 * i], w_pre[2 * i + 1]);
   for (int i = 0; i < n_post; ++i) lv.w_post.emplace_back(w_post[2 * i], w_post[2 * i + 1]);
   lv.rich = (n_pre + n_post) > 0;
+  return 0;
+}
+
+// ---- GPU-side setup of a hierarchy ------------------------------------------
+int sw_setup_testvectors(sw_engine* h, int hid, int level, int nvec, uint64_t seed, int sweeps,
+                         double tol, int maxiter, int precond, int32_t* iters_out) {
+  SWCHK(check_hier(h, hid, level, precond != 0));
+  if (nvec != SW_TV) return sw_fail(h, "the device setup works with %d test vectors per half", SW_TV);
+  if (sweeps < 0 || maxiter < 1) return sw_fail(h, "bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  Level& lv = H.lv[level];
+  if (lv.n <= 0 || (!lv.stencil && !lv.A.set)) return sw_fail(h, "level %d has no operator yet", level);
+  const int nbp = 64;
+  const size_t cnt = (size_t)lv.n * nbp;
+  if (!lv.tv2) SWCHK(dev_realloc(h, &lv.tv2, cnt));
+  if (!lv.tv || seed != 0) {
+    if (!lv.tv) SWCHK(dev_realloc(h, &lv.tv, cnt));
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_fill_random, dim3((lv.n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, lv.tv, lv.n, nbp, nvec,
+                       (unsigned long long)(seed ? seed : 7));
+    KLAUNCH_CHECK();
+  }
+  // the solver's own restart in both modes: ONE Krylov workspace (2 m + 2 vectors of 64 columns, tens
+  // of GB on a 1024^2 lattice) serves the setup and the solves that follow
+  const int m = std::min(h->restart, maxiter);
+  for (int sw = 0; sw < sweeps; ++sw) {
+    SWCHK(ensure_krylov(h, lv.sws, m, lv.n, nbp, true));
+    int total = 0;
+    // V <- A_l^-1 V (inexact): inverse iteration amplifies the near-kernel the coarse space must hold
+    SWCHK(fgmres(h, H, level, lv.tv, lv.tv2, tol, maxiter, m, true, lv.sws, nbp, &total, precond != 0));
+    SWCHK(stream_sync(h));
+    std::swap(lv.tv, lv.tv2);
+    if (iters_out) iters_out[sw] = total;
+  }
+  return 0;
+}
+
+int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, const int32_t* blk_rows,
+                      int G, int K, const int32_t* pcols, const int64_t* pmap) {
+  SWCHK(check_hier(h, hid, level, false));
+  Hier& H = h->hier[hid];
+  if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d", level);
+  if (!blk_rows || !pcols || !pmap || nblocks <= 0 || rpb <= 0) return sw_fail(h, "bad arguments");
+  if (rpb > 256) return sw_fail(h, "aggregate blocks of %d rows exceed the QR kernel's 256", rpb);
+  if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) return sw_fail(h, "bad group size %d", G);
+  HIPCHK(hipSetDevice(h->device));
+  Level& lf = H.lv[level];
+  Level& lc = H.lv[level + 1];
+  const int n_f = lf.n, n_c = nblocks * SW_TV;
+  if ((long long)nblocks * rpb != n_f) return sw_fail(h, "blocks do not tile level %d", level);
+  if (n_f % G) return sw_fail(h, "group size %d does not divide n = %d", G, n_f);
+  if (!lf.tv) return sw_fail(h, "level %d has no test vectors (sw_setup_testvectors)", level);
+  if (lc.n != 0 && lc.n != n_c) return sw_fail(h, "level %d already has n = %d", level + 1, lc.n);
+  if (!lc.h_rowmap.empty()) return sw_fail(h, "coarse level with a row permutation unsupported");
+  lc.n = n_c;
+  for (size_t i = 0; i < (size_t)nblocks * rpb; ++i)
+    if (blk_rows[i] < 0 || blk_rows[i] >= n_f) return sw_fail(h, "block member row out of range");
+  const int ng = n_f / G;
+  for (size_t i = 0; i < (size_t)ng * K; ++i)
+    if (pcols[i] < 0 || pcols[i] >= n_c) return sw_fail(h, "prolongator column out of range");
+  const long long qcount = (long long)nblocks * rpb * SW_TV;
+  for (size_t i = 0; i < (size_t)ng * K * G; ++i)
+    if (pmap[i] >= qcount) return sw_fail(h, "prolongator value map out of range");
+  SWCHK(free_op(h, lf.R));
+  SWCHK(free_op(h, lf.P));
+  // R = P^H in grouped-ELL form: group = block, G = SW_TV rows (the block's coarse dofs), K = rpb
+  EllOp& R = lf.R;
+  R.nrows = n_c;
+  R.ncols = n_f;
+  R.K = rpb;
+  R.G = SW_TV;
+  R.ngroups = nblocks;
+  SWCHK(upload(h, &R.cols, (const int*)blk_rows, (size_t)nblocks * rpb));
+  SWCHK(dev_realloc(h, &R.vals, (size_t)qcount));
+  cplx* Q = nullptr;
+  SWCHK(dev_realloc(h, &Q, (size_t)qcount));
+  {
+    LaunchScope ls(h, T_OTHER);
+    dim3 grid((nblocks + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK);
+#define QR_LAUNCH(RPL)                                                                           \
+  hipLaunchKernelGGL((swk::k_block_qr<RPL>), grid, dim3(SW_BLOCK), 0, h->stream,                 \
+                     (const cplx*)lf.tv, 64, (const int*)R.cols, nblocks, rpb, Q, R.vals)
+    if (rpb <= 64) QR_LAUNCH(1);
+    else if (rpb <= 128) QR_LAUNCH(2);
+    else QR_LAUNCH(4);
+#undef QR_LAUNCH
+    KLAUNCH_CHECK();
+  }
+  R.set = true;
+  // P: structure from the host (geometry), values gathered from Q
+  EllOp& P = lf.P;
+  P.nrows = n_f;
+  P.ncols = n_c;
+  P.K = K;
+  P.G = G;
+  P.ngroups = ng;
+  SWCHK(upload(h, &P.cols, (const int*)pcols, (size_t)ng * K));
+  const size_t pv = (size_t)ng * K * G;
+  SWCHK(dev_realloc(h, &P.vals, pv));
+  long long* dmap = nullptr;
+  SWCHK(upload(h, &dmap, (const long long*)pmap, pv));
+  {
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_fill_from_map, dim3(4096), dim3(SW_BLOCK), 0, h->stream,
+                       (const long long*)dmap, (const cplx*)Q, P.vals, pv);
+    KLAUNCH_CHECK();
+  }
+  P.set = true;
+  // the coarse image of the test vectors is the starting guess one level down
+  if (!lc.tv) SWCHK(dev_realloc(h, &lc.tv, (size_t)n_c * 64));
+  SWCHK(launch_ell(h, R, 0, lf.tv, nullptr, lc.tv, 64, T_R));
+  SWCHK(stream_sync(h));
+  SWCHK(dev_free(h, dmap));
+  SWCHK(dev_free(h, Q));
+  return 0;
+}
+
+int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* nbr) {
+  SWCHK(check_hier(h, hid, level, false));
+  Hier& H = h->hier[hid];
+  if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d", level);
+  if (!nbr || Lc < 4 || (Lc & 3)) return sw_fail(h, "coarse lattice extent %d must be a multiple of 4", Lc);
+  if (!h->use_mfma || !h->mfma_ops) return sw_fail(h, "the device setup needs use_mfma = mfma_ops = 1");
+  HIPCHK(hipSetDevice(h->device));
+  Level& lf = H.lv[level];
+  Level& lc = H.lv[level + 1];
+  const int ncs = Lc * Lc, n_c = ncs * 16, n_f = lf.n;
+  if (lc.n != n_c) return sw_fail(h, "level %d has n = %d, expected %d sites x 16", level + 1, lc.n, ncs);
+  if (!lf.P.set || !lf.R.set) return sw_fail(h, "transfer operators of level %d not set", level);
+  for (int i = 0; i < ncs * 5; ++i)
+    if (nbr[i] < 0 || nbr[i] >= ncs) return sw_fail(h, "neighbour site out of range");
+  for (int I = 0; I < ncs; ++I)
+    for (int a = 1; a < 5; ++a)
+      if (nbr[I * 5 + a] <= nbr[I * 5 + a - 1]) return sw_fail(h, "neighbour lists must be strictly increasing");
+  const int nbp = 256;
+  cplx *E = nullptr, *X = nullptr, *Y = nullptr;
+  SWCHK(dev_realloc(h, &E, (size_t)n_c * nbp));
+  SWCHK(dev_realloc(h, &X, (size_t)n_f * nbp));
+  SWCHK(dev_realloc(h, &Y, (size_t)n_f * nbp));
+  {
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_probe_unit, dim3((n_c + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, E, Lc, nbp);
+    KLAUNCH_CHECK();
+  }
+  SWCHK(launch_ell(h, lf.P, 0, E, nullptr, X, nbp, T_P));          // X = P E
+  SWCHK(apply_op(h, lf, 0, X, nullptr, Y, nbp));                   // Y = A X
+  SWCHK(launch_ell(h, lf.R, 0, Y, nullptr, E, nbp, T_R));          // Z = R Y  (over E)
+  int* dnbr = nullptr;
+  SWCHK(upload(h, &dnbr, (const int*)nbr, (size_t)ncs * 5));
+  SWCHK(free_op(h, lc.A));
+  EllOp& A = lc.A;
+  A.nrows = A.ncols = n_c;
+  A.bsr_KS = 20;
+  SWCHK(dev_realloc(h, &A.bsr_vals, (size_t)ncs * 20 * 64));
+  SWCHK(dev_realloc(h, &A.bsr_kcol, (size_t)ncs * 20));
+  {
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_bsr_from_probe, dim3((ncs * 20 + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)E, nbp, (const int*)dnbr, Lc,
+                       A.bsr_vals, A.bsr_kcol);
+    KLAUNCH_CHECK();
+  }
+  A.set = true;
+  SWCHK(stream_sync(h));
+  SWCHK(dev_free(h, dnbr));
+  SWCHK(dev_free(h, E));
+  SWCHK(dev_free(h, X));
+  SWCHK(dev_free(h, Y));
+  return 0;
+}
+
+// rocSOLVER (LU with partial pivoting, the device counterpart of np.linalg.inv at
+// multigrid.py:342-344), loaded on first use so that the library has no hard dependency on it
+namespace {
+struct RocSolver {
+  void* lib_blas = nullptr;
+  void* lib_solver = nullptr;
+  int (*create)(void**) = nullptr;
+  int (*destroy)(void*) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*zgetrf)(void*, int, int, void*, int, int*, int*) = nullptr;
+  int (*zgetri)(void*, int, void*, int, int*, int*) = nullptr;
+  bool tried = false, ok = false;
+};
+RocSolver g_rs;
+bool load_rocsolver() {
+  if (g_rs.tried) return g_rs.ok;
+  g_rs.tried = true;
+  g_rs.lib_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!g_rs.lib_blas) g_rs.lib_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  g_rs.lib_solver = dlopen("librocsolver.so", RTLD_NOW);
+  if (!g_rs.lib_solver) g_rs.lib_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW);
+  if (!g_rs.lib_blas || !g_rs.lib_solver) return false;
+  g_rs.create = (int (*)(void**))dlsym(g_rs.lib_blas, "rocblas_create_handle");
+  g_rs.destroy = (int (*)(void*))dlsym(g_rs.lib_blas, "rocblas_destroy_handle");
+  g_rs.set_stream = (int (*)(void*, hipStream_t))dlsym(g_rs.lib_blas, "rocblas_set_stream");
+  g_rs.zgetrf = (int (*)(void*, int, int, void*, int, int*, int*))dlsym(g_rs.lib_solver, "rocsolver_zgetrf");
+  g_rs.zgetri = (int (*)(void*, int, void*, int, int*, int*))dlsym(g_rs.lib_solver, "rocsolver_zgetri");
+  g_rs.ok = g_rs.create && g_rs.destroy && g_rs.set_stream && g_rs.zgetrf && g_rs.zgetri;
+  return g_rs.ok;
+}
+}  // namespace
+
+int sw_setup_invert_coarsest(sw_engine* h, int hid) {
+  SWCHK(check_hier(h, hid, 0, false));
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  Level& lv = H.lv[H.nlevels - 1];
+  const EllOp& A = lv.A;
+  if (H.nlevels < 2 || !A.set || A.bsr_KS <= 0) return sw_fail(h, "coarsest level has no block-row operator");
+  const int n = lv.n;
+  if (n % 16) return sw_fail(h, "coarsest size %d is not a multiple of 16", n);
+  if (!load_rocsolver()) return sw_fail(h, "rocSOLVER / rocBLAS could not be loaded (%s)", dlerror());
+  cplx* D = nullptr;
+  int* ipiv = nullptr;
+  SWCHK(dev_realloc(h, &D, (size_t)n * n));
+  SWCHK(dev_realloc(h, &ipiv, (size_t)n + 1));
+  HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
+  {
+    LaunchScope ls(h, T_OTHER);
+    const int items = (n / 16) * A.bsr_KS;
+    hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)A.bsr_vals, (const int*)A.bsr_kcol,
+                       n / 16, A.bsr_KS, n, D);
+    KLAUNCH_CHECK();
+  }
+  // the row-major buffer read column-major is D^T; (D^T)^-1 = (D^-1)^T, i.e. D^-1 row-major again
+  void* rb = nullptr;
+  if (g_rs.create(&rb) != 0 || !rb) return sw_fail(h, "rocblas_create_handle failed");
+  int rc = g_rs.set_stream(rb, h->stream);
+  int* info = ipiv + n;
+  if (rc == 0) rc = g_rs.zgetrf(rb, n, n, D, n, ipiv, info);
+  if (rc == 0) rc = g_rs.zgetri(rb, n, D, n, ipiv, info);
+  hipError_t se = hipStreamSynchronize(h->stream);
+  int hinfo = 0;
+  if (se == hipSuccess) se = hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost);
+  g_rs.destroy(rb);
+  if (rc != 0 || se != hipSuccess) return sw_fail(h, "rocSOLVER zgetrf/zgetri failed (status %d)", rc);
+  if (hinfo != 0) return sw_fail(h, "coarsest operator is singular (pivot %d)", hinfo);
+  SWCHK(free_op(h, H.cinv));
+  EllOp& op = H.cinv;
+  op.nrows = op.ncols = n;
+  const int KS = n / 4, RT = n / 16;
+  SWCHK(dev_realloc(h, &op.bsr_vals, (size_t)RT * KS * 64));
+  SWCHK(dev_realloc(h, &op.bsr_kcol, (size_t)RT * KS));
+  {
+    LaunchScope ls(h, T_OTHER);
+    const size_t items = (size_t)RT * KS;
+    hipLaunchKernelGGL(swk::k_dense_to_bsr, dim3((unsigned)((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK)),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)D, n, op.bsr_vals, op.bsr_kcol);
+    KLAUNCH_CHECK();
+  }
+  op.bsr_KS = KS;
+  op.set = true;
+  SWCHK(stream_sync(h));
+  SWCHK(dev_free(h, D));
+  SWCHK(dev_free(h, ipiv));
+  return 0;
+}
+
+int sw_get_level_dense(sw_engine* h, int hid, int level, double* dense) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (!dense) return sw_fail(h, "null output");
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[hid].lv[level];
+  const EllOp& A = lv.A;
+  if (!A.set || A.bsr_KS <= 0) return sw_fail(h, "level %d has no block-row operator", level);
+  const int n = lv.n, RT = n / 16, KS = A.bsr_KS;
+  std::vector<std::complex<double>> vals((size_t)RT * KS * 64);
+  std::vector<int> kcol((size_t)RT * KS);
+  SWCHK(stream_sync(h));
+  HIPCHK(hipMemcpy(vals.data(), A.bsr_vals, vals.size() * sizeof(cplx), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(kcol.data(), A.bsr_kcol, kcol.size() * sizeof(int), hipMemcpyDeviceToHost));
+  std::complex<double>* D = (std::complex<double>*)dense;
+  std::fill(D, D + (size_t)n * n, std::complex<double>(0, 0));
+  for (int rt = 0; rt < RT; ++rt)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = rt * 16 + (lane & 15), col = kcol[(size_t)rt * KS + ks] + (lane >> 4);
+        D[(size_t)row * n + col] += vals[((size_t)rt * KS + ks) * 64 + lane];
+      }
   return 0;
 }
 

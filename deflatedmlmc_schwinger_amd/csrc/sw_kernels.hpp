@@ -1043,6 +1043,168 @@ __global__ __launch_bounds__(SW_BLOCK) void k_defl_apply(const cplx* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// GPU-side multigrid setup (the device counterpart of multigrid.py:232-280:
+// per-aggregate orthonormalisation of the test vectors, R = P^H, A_c = R A P).
+// Test vectors of a level live in an ordinary level vector [n][nbp]: column = test vector.
+// ------------------------------------------------------------------------------------------
+#define SW_TV 8   // test vectors per chirality half (coarse sites carry 2 * SW_TV = 16 dofs = one MFMA tile)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One wave = one (aggregate, chirality) block of rpb rows x SW_TV columns: modified Gram-Schmidt,
+// two sweeps ("twice is enough"), columns normalised.  rows[b*rpb + p] = level row of member p.
+//   Q   [b][p][k]       (k fastest)  -> source of the prolongator values
+//   Rv  = conj(Q)       grouped-ELL values of R = P^H with G = SW_TV, K = rpb (cols = rows[])
+template <int RPL>   // rows per lane: rpb <= 64 * RPL
+__global__ __launch_bounds__(SW_BLOCK) void k_block_qr(const cplx* __restrict__ V, int nbp,
+                                                       const int* __restrict__ rows, int nblocks,
+                                                       int rpb, cplx* __restrict__ Q,
+                                                       cplx* __restrict__ Rv) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (b >= nblocks) return;
+  cplx m[RPL][SW_TV];
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int p = lane + 64 * q;
+#pragma unroll
+    for (int k = 0; k < SW_TV; ++k) m[q][k] = cmake(0.0, 0.0);
+    if (p < rpb) {
+      const cplx* src = V + (size_t)rows[(size_t)b * rpb + p] * nbp;
+#pragma unroll
+      for (int k = 0; k < SW_TV; ++k) m[q][k] = src[k];
+    }
+  }
+  for (int sweep = 0; sweep < 2; ++sweep) {
+#pragma unroll
+    for (int k = 0; k < SW_TV; ++k) {
+      double n2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) n2 += m[q][k].x * m[q][k].x + m[q][k].y * m[q][k].y;
+      n2 = wave_sum(n2);
+      const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) m[q][k] = cmake(m[q][k].x * inv, m[q][k].y * inv);
+#pragma unroll
+      for (int j = k + 1; j < SW_TV; ++j) {
+        cplx d = cmake(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) cfmac(d, m[q][k], m[q][j]);
+        d.x = wave_sum(d.x);
+        d.y = wave_sum(d.y);
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) cfma(m[q][j], cmake(-d.x, -d.y), m[q][k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) {
+    const int p = lane + 64 * q;
+    if (p < rpb) {
+      const size_t o = ((size_t)b * rpb + p) * SW_TV;
+#pragma unroll
+      for (int k = 0; k < SW_TV; ++k) {
+        Q[o + k] = m[q][k];
+        Rv[o + k] = cmake(m[q][k].x, -m[q][k].y);
+      }
+    }
+  }
+}
+
+// vals[i] = map[i] >= 0 ? Q[map[i]] : 0   (prolongator values into their grouped-ELL slots)
+__global__ __launch_bounds__(SW_BLOCK) void k_fill_from_map(const long long* __restrict__ map,
+                                                            const cplx* __restrict__ Q,
+                                                            cplx* __restrict__ vals, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    const long long s = map[i];
+    vals[i] = s >= 0 ? Q[s] : cmake(0.0, 0.0);
+  }
+}
+
+// Galerkin coarse operator by colour probing.  Coarse sites J = yc*Lc + xc carry 16 dofs; with the
+// 16 colours q(J) = (xc & 3) + 4 (yc & 3) the five sites of any 5-point neighbourhood have distinct
+// colours (Lc % 4 == 0), so the 256 columns col = 16 q + c of
+//   E[(J, c')][col] = [c == c'] [q(J) == q],    Z = R A P E
+// hold every block of A_c exactly once:  A_c[(I,i),(J,c)] = Z[(I,i)][16 q(J) + c]  for J ~ I.
+__global__ __launch_bounds__(SW_BLOCK) void k_probe_unit(cplx* __restrict__ E, int Lc, int nbp) {
+  // grid.x = coarse rows / 4, one wave per row; nbp == 256
+  const int row = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= Lc * Lc * 16) return;
+  const int lane = threadIdx.x & 63;
+  const int J = row >> 4, cp = row & 15;
+  const int q = ((J % Lc) & 3) + 4 * ((J / Lc) & 3);
+  for (int col = lane; col < nbp; col += 64)
+    E[(size_t)row * nbp + col] = cmake((col == 16 * q + cp) ? 1.0 : 0.0, 0.0);
+}
+
+// MFMA block-row form of A_c from Z: tile rt = coarse site I, k-step ks = 4 n + g for the n-th
+// neighbour site S (sorted list nbr[I][0..4]) and its column group g:
+//   vals[(rt*20 + ks)*64 + lane] = Z[(16 I + (lane & 15))][16 q(S) + 4 g + (lane >> 4)]
+__global__ __launch_bounds__(SW_BLOCK) void k_bsr_from_probe(const cplx* __restrict__ Z, int nbp,
+                                                             const int* __restrict__ nbr, int Lc,
+                                                             cplx* __restrict__ vals,
+                                                             int* __restrict__ kcol) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);   // (rt, ks)
+  if (item >= Lc * Lc * 20) return;
+  const int rt = item / 20, ks = item - rt * 20;
+  const int S = nbr[rt * 5 + (ks >> 2)];
+  const int q = ((S % Lc) & 3) + 4 * ((S / Lc) & 3);
+  const int g = ks & 3;
+  vals[(size_t)item * 64 + lane] =
+      Z[((size_t)rt * 16 + (lane & 15)) * nbp + 16 * q + 4 * g + (lane >> 4)];
+  if (lane == 0) kcol[item] = S * 16 + 4 * g;
+}
+
+// block-row operator -> dense row-major [n][n] (D zeroed by the caller); one wave per (rt, ks)
+__global__ __launch_bounds__(SW_BLOCK) void k_bsr_to_dense(const cplx* __restrict__ vals,
+                                                           const int* __restrict__ kcol, int RT,
+                                                           int KS, int n, cplx* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= RT * KS) return;
+  const int rt = item / KS;
+  const cplx v = vals[(size_t)item * 64 + lane];
+  if (v.x != 0.0 || v.y != 0.0)   // padding k-steps repeat column 0 with zero values
+    D[((size_t)rt * 16 + (lane & 15)) * n + kcol[item] + (lane >> 4)] = v;
+}
+
+// dense row-major [n][n] -> MFMA block-row form with every 4-column group (KS = n/4)
+__global__ __launch_bounds__(SW_BLOCK) void k_dense_to_bsr(const cplx* __restrict__ D, int n,
+                                                           cplx* __restrict__ vals,
+                                                           int* __restrict__ kcol) {
+  const int lane = threadIdx.x & 63;
+  const int KS = n >> 2;
+  const size_t item = (size_t)blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= (size_t)(n >> 4) * KS) return;
+  const int rt = (int)(item / KS), ks = (int)(item - (size_t)rt * KS);
+  vals[item * 64 + lane] = D[((size_t)rt * 16 + (lane & 15)) * n + 4 * ks + (lane >> 4)];
+  if (lane == 0) kcol[item] = 4 * ks;
+}
+
+// deterministic pseudo-random start vectors (splitmix64 of (seed, row, column)), entries in [-1,1)^2
+__global__ __launch_bounds__(SW_BLOCK) void k_fill_random(cplx* __restrict__ V, int n, int nbp,
+                                                          int ncols, unsigned long long seed) {
+  const int row = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int col = threadIdx.x & 63;
+  if (col >= nbp) return;
+  unsigned long long z = seed + 0x9e3779b97f4a7c15ull * ((unsigned long long)row * 64ull + col + 1ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  const double re = (double)(z & 0xffffffffull) / 2147483648.0 - 1.0;
+  const double im = (double)(z >> 32) / 2147483648.0 - 1.0;
+  V[(size_t)row * nbp + col] = (col < ncols) ? cmake(re, im) : cmake(0.0, 0.0);
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-probe scalar kernels of the batched flexible GMRES (one thread per probe).
 // Storage: H [(m+1)][m][nbp], cs [m][nbp] (.x), sn [m][nbp], g [(m+1)][nbp].
 // ------------------------------------------------------------------------------------------

@@ -67,6 +67,11 @@ def load_library():
     sig("sw_set_cycle", i32, vp, i32, i32, i32, i32, i32)
     sig("sw_set_smoother", i32, vp, i32, i32, i32, vp, i32, vp)
     sig("sw_set_gmres_smoother", i32, vp, i32, i32, i32, i32)
+    sig("sw_setup_testvectors", i32, vp, i32, i32, i32, C.c_uint64, i32, dbl, i32, i32, vp)
+    sig("sw_setup_transfer", i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp)
+    sig("sw_setup_galerkin", i32, vp, i32, i32, i32, vp)
+    sig("sw_get_level_dense", i32, vp, i32, i32, vp)
+    sig("sw_setup_invert_coarsest", i32, vp, i32)
     sig("sw_hier_end", i32, vp, i32)
     sig("sw_set_deflation", i32, vp, i32, vp)
     sig("sw_set_level_deflation", i32, vp, i32, i32, vp)
@@ -115,7 +120,8 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_set_smoother", "sw_set_gmres_smoother", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
+    "sw_set_smoother", "sw_set_gmres_smoother", "sw_setup_testvectors", "sw_setup_transfer",
+    "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -230,6 +236,40 @@ class Engine:
     def set_gmres_smoother(self, hid, level, m, cycles):
         self._chk(self._lib.sw_set_gmres_smoother(self._h, hid, level, int(m), int(cycles)),
                   "sw_set_gmres_smoother")
+
+    # -- GPU-side setup ---------------------------------------------------------------------
+    def setup_testvectors(self, hid, level, nvec, seed, sweeps, tol, maxiter, precond):
+        its = np.zeros(max(1, sweeps), dtype=np.int32)
+        self._chk(self._lib.sw_setup_testvectors(self._h, hid, level, nvec, int(seed), sweeps,
+                                                 float(tol), int(maxiter), 1 if precond else 0,
+                                                 _ptr(its)), "sw_setup_testvectors")
+        return its[:sweeps].tolist()
+
+    def setup_transfer(self, hid, level, blk_rows, G, pcols, pmap):
+        blk_rows = np.ascontiguousarray(blk_rows, dtype=np.int32)
+        pcols = np.ascontiguousarray(pcols, dtype=np.int32)
+        pmap = np.ascontiguousarray(pmap, dtype=np.int64)
+        nblocks, rpb = blk_rows.shape
+        K = pcols.shape[1]
+        self._chk(self._lib.sw_setup_transfer(self._h, hid, level, nblocks, rpb, _ptr(blk_rows), G, K,
+                                              _ptr(pcols), _ptr(pmap)), "sw_setup_transfer")
+        self.level_sizes[hid][level] = nblocks * rpb
+        self.level_sizes[hid][level + 1] = nblocks * 8
+
+    def setup_galerkin(self, hid, level, Lc, nbr):
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        self._chk(self._lib.sw_setup_galerkin(self._h, hid, level, int(Lc), _ptr(nbr)),
+                  "sw_setup_galerkin")
+
+    def setup_invert_coarsest(self, hid):
+        self._chk(self._lib.sw_setup_invert_coarsest(self._h, hid), "sw_setup_invert_coarsest")
+        self.level_sizes[hid][-1] = self.level_sizes[hid][-1]
+
+    def level_dense(self, hid, level):
+        n = self.level_sizes[hid][level]
+        M = np.empty((n, n), dtype=np.complex128)
+        self._chk(self._lib.sw_get_level_dense(self._h, hid, level, _ptr(M)), "sw_get_level_dense")
+        return M
 
     def hier_end(self, hid):
         self._chk(self._lib.sw_hier_end(self._h, hid), "sw_hier_end")

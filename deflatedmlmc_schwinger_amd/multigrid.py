@@ -210,6 +210,19 @@ class MG:
             if hit is not None:
                 testvectors = [hit["tv%d" % i] for i in range(len(cfg["coarsening"]))]
                 skey = None
+        if cfg.get("setup", "eigs") == "device":
+            # everything on the GPU, per engine (deterministic kernels: identical on every handle)
+            from . import setup_gpu
+            info = None
+            for eng in self.engines:
+                info = setup_gpu.device_solver_hierarchy(eng, lat, cfg, SOLVER_HID)
+                eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
+            self._have_solver_hier = True
+            self.solver_hier = None
+            self.solver_testvectors = None
+            self.solver_info = {"levels": info["levels"], "setup_s": time.time() - t0, "cfg": cfg,
+                                "setup_log": info["setup_log"]}
+            return
         comm = _dist.default_comm()
         A0 = self.ml.levels[0].A
         if A0 is None:

@@ -71,3 +71,184 @@ def adaptive_solver_hierarchy(eng, A0, lat, cfg, hid):
     cinv = np.linalg.inv(As[-1].toarray())
     return {"A": As, "P": Ps, "coarsest_inv": cinv, "tv": tvs, "cfg": cfg,
             "setup_log": log, "setup_s": time.time() - t0}
+
+
+# ----------------------------------------------------------------------------------------------
+# everything on the device: test vectors, per-aggregate QR, P / R, Galerkin products
+# ----------------------------------------------------------------------------------------------
+def level_geometry(Lf, hd, agg, fine_level):
+    """Index geometry of one coarsening step (agg x agg site aggregates with a chirality split, as
+    hierarchy._site_prolongator): which engine rows form each (aggregate, half) block, and the
+    grouped-ELL structure of the prolongator over them.
+
+    Level 0 rows are in the engine's even-odd order ((par*V/2 + site/2)*2 + half), coarse levels in
+    site-major order ((site*2 + half)*hd + k).  Returns dict(blk_rows[nblocks, rpb], G, pcols[ng, K],
+    pmap[ng, K, G], Lc, nbr[Lc*Lc, 5])."""
+    if Lf % agg:
+        raise Exception("lattice extent %d not divisible by aggregate edge %d" % (Lf, agg))
+    V = Lf * Lf
+    n = 2 * V * hd
+    idx = np.arange(n, dtype=np.int64)
+    if fine_level:
+        if hd != 1:
+            raise Exception("level 0 carries one dof per spin")
+        half = idx // V
+        site = idx % V
+        x, y = site % Lf, site // Lf
+        internal = (((x + y) & 1) * (V // 2) + (site >> 1)) * 2 + half
+    else:
+        site = idx // (2 * hd)
+        half = (idx // hd) % 2
+        x, y = site % Lf, site // Lf
+        internal = idx
+    Lc = Lf // agg
+    block = ((y // agg) * Lc + (x // agg)) * 2 + half
+    nblocks = 2 * Lc * Lc
+    rpb = n // nblocks
+    order = np.argsort(block, kind="stable")
+    blk_rows = internal[order].reshape(nblocks, rpb)
+    blk_of = np.empty(n, dtype=np.int64)
+    pos_of = np.empty(n, dtype=np.int64)
+    blk_of[blk_rows] = np.arange(nblocks)[:, None]
+    pos_of[blk_rows] = np.arange(rpb)[None, :]
+    G = 4 if fine_level else 8
+    ng = n // G
+    rb = blk_of.reshape(ng, G)
+    b0, b1 = rb.min(axis=1), rb.max(axis=1)
+    if not ((rb == b0[:, None]) | (rb == b1[:, None])).all():
+        raise Exception("a row group of the prolongator touches more than two blocks")
+    two = bool((b0 != b1).any())
+    K = 16 if two else 8
+    k8 = np.arange(8)
+    pcols = np.empty((ng, K), dtype=np.int64)
+    pcols[:, :8] = b0[:, None] * 8 + k8[None, :]
+    if two:
+        pcols[:, 8:] = b1[:, None] * 8 + k8[None, :]
+    rows = np.arange(n).reshape(ng, G)                       # engine row of (group, g)
+    src = (blk_of[rows] * rpb + pos_of[rows]) * 8            # [ng, G]
+    pmap = np.full((ng, K, G), -1, dtype=np.int64)
+    own0 = rb == b0[:, None]
+    pmap[:, :8, :] = np.where(own0[:, None, :], src[:, None, :] + k8[None, :, None], -1)
+    if two:
+        own1 = (rb == b1[:, None]) & (b1 != b0)[:, None]
+        pmap[:, 8:, :] = np.where(own1[:, None, :], src[:, None, :] + k8[None, :, None], -1)
+    cs = np.arange(Lc * Lc)
+    xc, yc = cs % Lc, cs // Lc
+    nbr = np.stack([cs, yc * Lc + (xc + 1) % Lc, yc * Lc + (xc - 1) % Lc,
+                    ((yc + 1) % Lc) * Lc + xc, ((yc - 1) % Lc) * Lc + xc], axis=1)
+    nbr = np.sort(nbr, axis=1)
+    return {"blk_rows": blk_rows, "G": G, "pcols": pcols, "pmap": pmap, "Lc": Lc, "nbr": nbr,
+            "n_c": nblocks * 8}
+
+
+class _EngineOperator:
+    """A level operator of an engine hierarchy as something hierarchy.smoother_weights can use."""
+
+    def __init__(self, eng, hid, level, n):
+        self.eng, self.hid, self.level = eng, hid, level
+        self.shape = (n, n)
+
+    def __matmul__(self, v):
+        return self.eng.apply_dirac(self.hid, self.level, np.asarray(v, dtype=np.complex128))
+
+
+def device_solver_hierarchy(eng, lat, cfg, hid):
+    """The solver hierarchy built ON THE GPU (solver_cfg["setup"] = "device"): test vectors by
+    batched inverse iteration (first unpreconditioned on each new level, then one refinement pass
+    preconditioned by the hierarchy itself), per-aggregate QR, P / R and the Galerkin operators
+    A_{l+1} = R A P by colour probing, all with engine kernels; the host only supplies index
+    geometry, inverts the coarsest operator and finds the smoother polynomials.
+    Requires 8 test vectors per half on every coarsening and coarse extents that are multiples of 4."""
+    L, mass, U1, U2 = lat
+    coarsening = [tuple(c) for c in cfg["coarsening"]]
+    for agg, nvec in coarsening:
+        if nvec != 8:
+            raise Exception("the device setup needs 8 test vectors per chirality half")
+    nl = len(coarsening) + 1
+    sweeps = int(cfg.get("setup_sweeps", 3))
+    tol = float(cfg.get("setup_tol", 0.1))
+    maxiter = int(cfg.get("setup_maxiter", 32))
+    refine = int(cfg.get("setup_refine", 1))
+    seed = int(cfg.get("setup_seed", 7))
+    t0 = time.time()
+    log = []
+    geo = []
+    clock = {"geometry": 0.0, "testvectors": 0.0, "transfer+galerkin": 0.0, "coarsest_inverse": 0.0,
+             "smoother_polynomials": 0.0}
+
+    class _timed:
+        def __init__(self, key):
+            self.key = key
+
+        def __enter__(self):
+            self.t = time.time()
+
+        def __exit__(self, *exc):
+            clock[self.key] += time.time() - self.t
+
+    Lf, hd = L, 1
+    with _timed("geometry"):
+        for lvl, (agg, nvec) in enumerate(coarsening):
+            geo.append(level_geometry(Lf, hd, agg, lvl == 0))
+            Lf //= agg
+            hd = nvec
+    sizes = [2 * L * L] + [g["n_c"] for g in geo]
+
+    def rebuild_operators(level):
+        """P_l, R_l, A_{l+1} for l >= level from the test vectors in place (device only)."""
+        with _timed("transfer+galerkin"):
+            for lv in range(level, nl - 1):
+                g = geo[lv]
+                eng.setup_transfer(hid, lv, g["blk_rows"], g["G"], g["pcols"], g["pmap"])
+                eng.setup_galerkin(hid, lv, g["Lc"], g["nbr"])
+
+    def finish():
+        """coarsest inverse (host, as multigrid.py:342-344), cycle shapes, smoother polynomials."""
+        with _timed("coarsest_inverse"):
+            if cfg.get("setup_inverse", "device") == "device":
+                eng.setup_invert_coarsest(hid)                 # rocSOLVER LU on the GPU
+            else:
+                eng.set_coarsest_inv(hid, _hier.dense_inverse(eng.level_dense(hid, nl - 1)))
+            eng.hier_end(hid)
+        with _timed("smoother_polynomials"):
+            for lv in range(nl - 1):
+                cyc = cfg["cycle"][lv]
+                eng.set_cycle(hid, lv, cyc[0], cyc[1], cyc[2])
+                if cfg.get("smoother", "richardson") == "richardson":
+                    op = _EngineOperator(eng, hid, lv, sizes[lv])
+                    eng.set_smoother(hid, lv, _hier.smoother_weights(op, cyc[0]),
+                                     _hier.smoother_weights(op, cyc[1]))
+
+    eng.hier_begin(hid, nl)
+    eng.set_lattice(hid, L, mass, U1, U2)
+    eng.set_solver(int(cfg.get("restart", 24)), hid)      # fixes the Krylov workspace shape
+    # pass 1: top-down, each new level's test vectors by unpreconditioned inverse iteration
+    for lvl in range(nl - 1):
+        t1 = time.time()
+        with _timed("testvectors"):
+            its = eng.setup_testvectors(hid, lvl, 8, seed if lvl == 0 else 0, sweeps, tol, maxiter,
+                                        False)
+        log.append({"pass": 1, "level": lvl, "n": sizes[lvl], "gmres_iterations": its,
+                    "seconds": round(time.time() - t1, 3)})
+        g = geo[lvl]
+        with _timed("transfer+galerkin"):
+            eng.setup_transfer(hid, lvl, g["blk_rows"], g["G"], g["pcols"], g["pmap"])
+            eng.setup_galerkin(hid, lvl, g["Lc"], g["nbr"])
+    finish()
+    eng.set_solver(int(cfg.get("restart", 24)), hid)
+    # pass 2: refinement, preconditioned by the hierarchy itself (a few iterations per solve)
+    refine_levels = int(cfg.get("setup_refine_levels", 1))     # how many levels (from the top) refine
+    for _ in range(refine):
+        for lvl in range(min(refine_levels, nl - 1)):
+            t1 = time.time()
+            with _timed("testvectors"):
+                its = eng.setup_testvectors(hid, lvl, 8, 0, 1, float(cfg.get("setup_refine_tol", 1e-2)),
+                                            int(cfg.get("setup_refine_maxiter", 64)), True)
+            log.append({"pass": 2, "level": lvl, "n": sizes[lvl], "gmres_iterations": its,
+                        "seconds": round(time.time() - t1, 3)})
+            # new P_lvl => new coarse basis: every operator below is rebuilt from the restricted
+            # vectors, and the dense coarsest inverse with them
+            rebuild_operators(lvl)
+            finish()
+    log.append({"seconds": {k: round(v, 3) for k, v in clock.items()}})
+    return {"levels": sizes, "setup_log": log, "setup_s": time.time() - t0, "cfg": cfg}

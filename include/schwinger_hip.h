@@ -77,6 +77,35 @@ int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w
  * lgmres(A_l, r, tol=1e-20, maxiter=smooth_iters=2) with SciPy's inner_m = 30 (SURVEY F5;
  * LGMRES's single augmentation vector in the second cycle is not reproduced).  m = 0 switches back. */
 int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles);
+/* ---- GPU-side setup of a hierarchy (device counterpart of multigrid.py:157-280) ----
+ * The test vectors of a level stay in HBM.  Coarse levels built this way carry 16 dofs per coarse
+ * site (8 test vectors x 2 chirality halves), i.e. one MFMA row tile per site.
+ * sw_setup_testvectors: `sweeps` rounds of V <- A_level^-1 V by batched flexible GMRES to `tol`
+ *   (precond = 0: unpreconditioned, for a hierarchy still under construction; 1: with the finished
+ *   hierarchy's own cycle from `level` down).  seed != 0 starts from pseudo-random vectors, seed = 0
+ *   from the vectors the level already holds (the restricted ones of the level above).
+ *   iters_out[sweeps] receives the iteration counts.  Replaces eigs(A_l, k, sigma=0), multigrid.py:174.
+ * sw_setup_transfer: per-(aggregate, half) orthonormalisation of the level's test vectors on the
+ *   device (multigrid.py:232-259), P_level and R_level = P^H from it (multigrid.py:262-274), and
+ *   the restricted test vectors as level+1's start.  blk_rows[nblocks*rpb]: level rows (engine row
+ *   order) of each block; P's grouped-ELL structure comes from the caller's geometry: group size
+ *   G, K columns per group pcols[ngroups*K], and pmap[ngroups*K*G] = index (block*rpb + member)*8 + k
+ *   of the value, or -1.
+ * sw_setup_galerkin: A_{level+1} = R A P (multigrid.py:276-280) by 16-colour probing with the
+ *   engine's own operator kernels, written straight into MFMA block-row form.  nbr[ncs*5]: the five
+ *   sites of each coarse site's 5-point neighbourhood, strictly increasing.
+ * sw_get_level_dense: a device-built level operator as a dense row-major complex128[n*n] (for the
+ *   host inverse of the coarsest level, multigrid.py:342-344). */
+int sw_setup_testvectors(sw_engine* h, int hid, int level, int nvec, uint64_t seed, int sweeps,
+                         double tol, int maxiter, int precond, int32_t* iters_out);
+int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, const int32_t* blk_rows,
+                      int G, int K, const int32_t* pcols, const int64_t* pmap);
+int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* nbr);
+int sw_get_level_dense(sw_engine* h, int hid, int level, double* dense);
+/* Dense inverse of a device-built coarsest operator without leaving the GPU: rocSOLVER LU
+ * (zgetrf + zgetri, loaded on first use) on the stream of the engine, result packed into the MFMA
+ * block-row form sw_set_coarsest_inv would upload (np.linalg.inv at multigrid.py:342-344). */
+int sw_setup_invert_coarsest(sw_engine* h, int hid);
 /* Mark the hierarchy complete (allocates level workspaces lazily). */
 int sw_hier_end(sw_engine* h, int hid);
 

@@ -309,3 +309,41 @@ def test_singular_vector_test_vectors_give_a_g3_compatible_hierarchy(A16, tv_typ
     assert np.linalg.norm(Qv - lam * v) < 1e-7 * np.linalg.norm(v)
     smin = np.linalg.svd(A16.toarray(), compute_uv=False)[-1]
     assert abs(abs(lam) - smin) < 1e-6 * smin + 1e-9 or abs(lam) < 10 * smin
+
+
+@pytest.mark.parametrize("Lf,hd,agg,fine", [(16, 1, 4, True), (8, 8, 2, False), (16, 8, 4, False)])
+def test_device_setup_geometry_reproduces_the_host_prolongator(Lf, hd, agg, fine):
+    """setup_gpu.level_geometry (block membership + grouped-ELL structure handed to
+    sw_setup_transfer) against hierarchy._site_prolongator: with the same per-block Q the
+    prolongator is identical entry for entry."""
+    from deflatedmlmc_schwinger_amd import setup_gpu
+    g = setup_gpu.level_geometry(Lf, hd, agg, fine)
+    n = 2 * Lf * Lf * hd
+    rng = np.random.default_rng(1)
+    tv = rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8))
+    P = hierarchy._site_prolongator(sp.identity(n, dtype=np.complex128, format='csr'), Lf, hd, agg, 8,
+                                    tv, fine)
+    idx = np.arange(n)
+    if fine:
+        V = Lf * Lf
+        half, site = idx // V, idx % V
+        x, y = site % Lf, site // Lf
+        internal = (((x + y) & 1) * (V // 2) + (site >> 1)) * 2 + half
+    else:
+        internal = idx
+    tvi = np.empty_like(tv)
+    tvi[internal] = tv
+    nblocks, rpb = g["blk_rows"].shape
+    assert sorted(g["blk_rows"].reshape(-1).tolist()) == list(range(n))      # a partition of the rows
+    Q = np.stack([np.linalg.qr(tvi[g["blk_rows"][b]])[0] for b in range(nblocks)]).reshape(-1)
+    vals = np.where(g["pmap"] >= 0, Q[np.clip(g["pmap"], 0, None)], 0)
+    xc = rng.standard_normal(g["n_c"]) + 1j * rng.standard_normal(g["n_c"])
+    y_dev = np.einsum('gkr,gk->gr', vals, xc[g["pcols"]]).reshape(-1)
+    y_ref = np.empty(n, complex)
+    y_ref[internal] = P @ xc
+    assert np.abs(y_dev - y_ref).max() == 0.0
+    # neighbour lists: five distinct sites with distinct probing colours
+    Lc = g["Lc"]
+    nbr = g["nbr"]
+    col = (nbr % Lc) % 4 + 4 * ((nbr // Lc) % 4)
+    assert all(len(set(r)) == 5 for r in nbr.tolist()) and all(len(set(r)) == 5 for r in col.tolist())

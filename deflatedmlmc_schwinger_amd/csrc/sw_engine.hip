@@ -126,6 +126,7 @@ struct sw_engine {
   int restart = 24;
   int solver_hid = 0;
   bool use_mfma = true;
+  int bsr_stages = 4, dense_stages = 8;   // software-pipeline depth of k_bsr_mfma (k-steps in flight)
   int bsr_map = 1, bsr_sub = 8, dense_map = 0;   // block orderings of k_bsr_mfma (see the kernel)
   bool bsr_nt = true;     // non-temporal B loads / Y stores in k_bsr_mfma on level operators
   bool ell_order = true;   // visit prolongator row groups sorted by column (A/B switch)
@@ -133,6 +134,7 @@ struct sw_engine {
   int bench_mode = 0;      // operator mode sw_bench_dirac times (0: Y=AX, 1: residual, 2: smoother step)
   bool mfma_ops = true;   // MFMA block-row kernel also for block-structured level operators
   int mfma_tiles = 4;
+  int mfma_small_tiles = 2;   // tiles per wave for operators too small to fill the chip (0: off)
   // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
@@ -372,35 +374,50 @@ static int free_op(sw_engine* h, EllOp& op) {
 static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B, cplx* Y,
                       int nbp, int cat, cplx w) {
   const int RT = op.nrows / 16;
-  const int NT = h->mfma_tiles;   // MFMA column tiles per wave (8 probes each)
+  // MFMA column tiles per wave (8 probes each).  Small operators (a 4096-row level on 256 probes is
+  // 2048 waves at NT = 4, two per SIMD once) are latency-bound: fewer tiles per wave = more waves
+  int NT = h->mfma_tiles;
+  if (h->mfma_small_tiles > 0 && cat != T_COARSEST &&
+      (long long)RT * ((2 * nbp) / (16 * NT)) < 4096)
+    NT = h->mfma_small_tiles;
   const int bmap = (cat == T_COARSEST) ? h->dense_map : h->bsr_map, msub = h->bsr_sub;
   const int RBn = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, NCn = (2 * nbp) / (16 * NT);
+  const int want = (cat == T_COARSEST) ? h->dense_stages : h->bsr_stages;
+  const int stages = (want >= 8 && op.bsr_KS % 8 == 0) ? 8 : ((want >= 4 && op.bsr_KS % 4 == 0) ? 4 : 2);
   dim3 grid = (bmap == 0) ? dim3(RBn, NCn) : dim3(RBn * NCn);
   LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE : (cat == T_MVM ? T_MFMA_OP : cat));
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
+#define BSR_LAUNCH_S(MD, NTT, NTB, SG)                                                           \
+  hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, NTB, SG>), grid, dim3(SW_BLOCK), 0, h->stream,   \
+                     (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br,   \
+                     Yr, 2 * nbp, nbp, w, bmap, msub)
 #define BSR_LAUNCH(MD, NTT)                                                                     \
   do {                                                                                          \
-    if (h->bsr_nt && cat != T_COARSEST)                                                         \
-      hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, true>), grid, dim3(SW_BLOCK), 0, h->stream,  \
-                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, \
-                         Yr, 2 * nbp, nbp, w, bmap, msub);                                      \
-    else                                                                                        \
-      hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, false>), grid, dim3(SW_BLOCK), 0, h->stream, \
-                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br, \
-                         Yr, 2 * nbp, nbp, w, bmap, msub);                                      \
+    const bool ntio_ = h->bsr_nt && cat != T_COARSEST;                                          \
+    if (stages == 8) {                                                                          \
+      if (ntio_) BSR_LAUNCH_S(MD, NTT, true, 8);                                                \
+      else BSR_LAUNCH_S(MD, NTT, false, 8);                                                     \
+    } else if (stages == 4) {                                                                   \
+      if (ntio_) BSR_LAUNCH_S(MD, NTT, true, 4);                                                \
+      else BSR_LAUNCH_S(MD, NTT, false, 4);                                                     \
+    } else {                                                                                    \
+      if (ntio_) BSR_LAUNCH_S(MD, NTT, true, 2);                                                \
+      else BSR_LAUNCH_S(MD, NTT, false, 2);                                                     \
+    }                                                                                           \
   } while (0)
-  if (NT == 8) {
-    if (mode == 0) BSR_LAUNCH(0, 8);
-    else if (mode == 1) BSR_LAUNCH(1, 8);
-    else BSR_LAUNCH(3, 8);
+  if (NT == 2) {
+    if (mode == 0) BSR_LAUNCH(0, 2);
+    else if (mode == 1) BSR_LAUNCH(1, 2);
+    else BSR_LAUNCH(3, 2);
   } else {
     if (mode == 0) BSR_LAUNCH(0, 4);
     else if (mode == 1) BSR_LAUNCH(1, 4);
     else BSR_LAUNCH(3, 4);
   }
 #undef BSR_LAUNCH
+#undef BSR_LAUNCH_S
   KLAUNCH_CHECK();
   return 0;
 }
@@ -1688,6 +1705,11 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     }
     return 0;
   }
+  if (std::strcmp(name, "bsr_stages") == 0 || std::strcmp(name, "dense_stages") == 0) {
+    if (value != 2.0 && value != 4.0 && value != 8.0) return sw_fail(h, "%s must be 2, 4 or 8", name);
+    (name[0] == 'd' ? h->dense_stages : h->bsr_stages) = (int)value;
+    return 0;
+  }
   if (std::strcmp(name, "bsr_nt") == 0) {
     h->bsr_nt = value != 0.0;
     return 0;
@@ -1744,8 +1766,14 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->mfma_ops = value != 0.0;
     return 0;
   }
+  if (std::strcmp(name, "mfma_small_tiles") == 0) {
+    if (value != 0.0 && value != 2.0 && value != 4.0)
+      return sw_fail(h, "mfma_small_tiles must be 0, 2 or 4");
+    h->mfma_small_tiles = (int)value;
+    return 0;
+  }
   if (std::strcmp(name, "mfma_tiles") == 0) {
-    if (value != 4.0 && value != 8.0) return sw_fail(h, "mfma_tiles must be 4 or 8");
+    if (value != 2.0 && value != 4.0) return sw_fail(h, "mfma_tiles must be 2 or 4");
     h->mfma_tiles = (int)value;
     return 0;
   }

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 // ------------------------------------------------------------------------------------------
 typedef double sw_double4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int NT, bool NTIO = false>
+template <int MODE, int NT, bool NTIO = false, int STG = 2>
 __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ Ap,
                                                        const int* __restrict__ kcol, int KS,
                                                        int RT, const double* __restrict__ Xr,
@@ -486,9 +486,11 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
     re[t] = sw_double4{0.0, 0.0, 0.0, 0.0};
     im[t] = re[t];
   }
-  // Two named register stages (KS is even): the loads of k-step ks+2 are issued right behind
-  // the 16 MFMAs of k-step ks and have a whole k-step of matrix work to land; the
-  // sched_barriers keep hipcc from sinking the loads below the next MFMA block.
+  // STG register stages (KS % STG == 0): the loads of k-step ks+STG are issued right behind the
+  // MFMAs of k-step ks and have STG-1 k-steps of matrix work to land (SQ counters of the 2-stage
+  // version on the level-1 operator: waves parked at s_waitcnt 31 % of their cycles, matrix pipe
+  // busy 36 % -- one k-step of MFMAs, 0.4 us for the wave pair, does not cover an L2/fabric round
+  // trip); the sched_barriers keep hipcc from sinking the loads below the next MFMA block.
 #define SW_BSR_LOAD(M_, X_, KSI)                               \
   {                                                            \
     M_ = a[(size_t)(KSI) * 64];                                \
@@ -500,21 +502,19 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
     re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.x, X_[t], re[t], 0, 0, 0);     \
     im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.y, X_[t], im[t], 0, 0, 0);     \
   }
-  cplx m0, m1;
-  double x0[NT], x1[NT];
-  SW_BSR_LOAD(m0, x0, 0);
-  SW_BSR_LOAD(m1, x1, 1);
-  for (int ks = 0; ks < KS; ks += 2) {
-    const int k2 = (ks + 2 < KS) ? ks + 2 : ks;
-    const int k3 = (ks + 3 < KS) ? ks + 3 : ks + 1;
-    __builtin_amdgcn_sched_barrier(0);
-    SW_BSR_MFMA(m0, x0);
-    __builtin_amdgcn_sched_barrier(0);
-    SW_BSR_LOAD(m0, x0, k2);
-    __builtin_amdgcn_sched_barrier(0);
-    SW_BSR_MFMA(m1, x1);
-    __builtin_amdgcn_sched_barrier(0);
-    SW_BSR_LOAD(m1, x1, k3);
+  cplx mm[STG];
+  double xx[STG][NT];
+#pragma unroll
+  for (int s = 0; s < STG; ++s) SW_BSR_LOAD(mm[s], xx[s], s);
+  for (int ks = 0; ks < KS; ks += STG) {
+#pragma unroll
+    for (int s = 0; s < STG; ++s) {
+      const int kn = (ks + s + STG < KS) ? ks + s + STG : ks + s;   // tail: harmless re-load
+      __builtin_amdgcn_sched_barrier(0);
+      SW_BSR_MFMA(mm[s], xx[s]);
+      __builtin_amdgcn_sched_barrier(0);
+      SW_BSR_LOAD(mm[s], xx[s], kn);
+    }
   }
 #undef SW_BSR_LOAD
 #undef SW_BSR_MFMA

@@ -48,6 +48,7 @@ enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER
                 T_MFMA_DENSE,   // k_bsr_mfma on the dense coarsest inverse
                 T_MFMA_OP,      // k_bsr_mfma on a block-structured level operator
                 T_STENCIL_SM2,  // k_stencil_2step: two fused smoother steps
+                T_MFMA_OP2,     // k_bsr_mfma on level operators below level 1 of the solver hierarchy
                 T_NCAT };
 // classes >= T_STENCIL are folded into the mvm / coarsest buckets by sw_timers and reported
 // separately by sw_kernel_stats
@@ -377,15 +378,18 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   // MFMA column tiles per wave (8 probes each).  Small operators (a 4096-row level on 256 probes is
   // 2048 waves at NT = 4, two per SIMD once) are latency-bound: fewer tiles per wave = more waves
   int NT = h->mfma_tiles;
-  if (h->mfma_small_tiles > 0 && cat != T_COARSEST &&
-      (long long)RT * ((2 * nbp) / (16 * NT)) < 4096)
+  if (h->mfma_small_tiles > 0 && (long long)RT * ((2 * nbp) / (16 * NT)) < 4096)
     NT = h->mfma_small_tiles;
   const int bmap = (cat == T_COARSEST) ? h->dense_map : h->bsr_map, msub = h->bsr_sub;
   const int RBn = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, NCn = (2 * nbp) / (16 * NT);
   const int want = (cat == T_COARSEST) ? h->dense_stages : h->bsr_stages;
   const int stages = (want >= 8 && op.bsr_KS % 8 == 0) ? 8 : ((want >= 4 && op.bsr_KS % 4 == 0) ? 4 : 2);
   dim3 grid = (bmap == 0) ? dim3(RBn, NCn) : dim3(RBn * NCn);
-  LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE : (cat == T_MVM ? T_MFMA_OP : cat));
+  // level-1 operator of the solver hierarchy vs. the smaller operators below it (separate stats)
+  const int n1 = h->hier[h->solver_hid].nlevels > 1 ? h->hier[h->solver_hid].lv[1].n : 0;
+  LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE
+                                      : (cat == T_MVM ? (op.nrows == n1 || n1 == 0 ? T_MFMA_OP : T_MFMA_OP2)
+                                                      : cat));
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
@@ -1402,7 +1406,7 @@ int sw_setup_testvectors(sw_engine* h, int hid, int level, int nvec, uint64_t se
 }
 
 int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, const int32_t* blk_rows,
-                      int G, int K, const int32_t* pcols, const int64_t* pmap) {
+                      int G, int K, const int32_t* pcols, const int64_t* pmap, const int32_t* porder) {
   SWCHK(check_hier(h, hid, level, false));
   Hier& H = h->hier[hid];
   if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d", level);
@@ -1461,6 +1465,14 @@ int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, co
   P.G = G;
   P.ngroups = ng;
   SWCHK(upload(h, &P.cols, (const int*)pcols, (size_t)ng * K));
+  if (porder) {
+    std::vector<char> seen(ng, 0);
+    for (int i = 0; i < ng; ++i) {
+      if (porder[i] < 0 || porder[i] >= ng || seen[porder[i]]) return sw_fail(h, "porder is not a permutation");
+      seen[porder[i]] = 1;
+    }
+    SWCHK(upload(h, &P.order, (const int*)porder, (size_t)ng));
+  }
   const size_t pv = (size_t)ng * K * G;
   SWCHK(dev_realloc(h, &P.vals, pv));
   long long* dmap = nullptr;
@@ -2421,7 +2433,7 @@ int sw_timers(sw_engine* h, double t[8]) {
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
   t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP] +
-              h->tacc[T_STENCIL_SM2];
+              h->tacc[T_STENCIL_SM2] + h->tacc[T_MFMA_OP2];
   t[T_COARSEST] += h->tacc[T_MFMA_DENSE];
   return 0;
 }

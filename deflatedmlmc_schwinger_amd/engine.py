@@ -68,7 +68,7 @@ def load_library():
     sig("sw_set_smoother", i32, vp, i32, i32, i32, vp, i32, vp)
     sig("sw_set_gmres_smoother", i32, vp, i32, i32, i32, i32)
     sig("sw_setup_testvectors", i32, vp, i32, i32, i32, C.c_uint64, i32, dbl, i32, i32, vp)
-    sig("sw_setup_transfer", i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp)
+    sig("sw_setup_transfer", i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp)
     sig("sw_setup_galerkin", i32, vp, i32, i32, i32, vp)
     sig("sw_get_level_dense", i32, vp, i32, i32, vp)
     sig("sw_setup_invert_coarsest", i32, vp, i32)
@@ -245,14 +245,18 @@ class Engine:
                                                  _ptr(its)), "sw_setup_testvectors")
         return its[:sweeps].tolist()
 
-    def setup_transfer(self, hid, level, blk_rows, G, pcols, pmap):
+    def setup_transfer(self, hid, level, blk_rows, G, pcols, pmap, porder=None):
         blk_rows = np.ascontiguousarray(blk_rows, dtype=np.int32)
         pcols = np.ascontiguousarray(pcols, dtype=np.int32)
         pmap = np.ascontiguousarray(pmap, dtype=np.int64)
         nblocks, rpb = blk_rows.shape
         K = pcols.shape[1]
+        if porder is not None:
+            porder = np.ascontiguousarray(porder, dtype=np.int32)
         self._chk(self._lib.sw_setup_transfer(self._h, hid, level, nblocks, rpb, _ptr(blk_rows), G, K,
-                                              _ptr(pcols), _ptr(pmap)), "sw_setup_transfer")
+                                              _ptr(pcols), _ptr(pmap),
+                                              _ptr(porder) if porder is not None else None),
+                  "sw_setup_transfer")
         self.level_sizes[hid][level] = nblocks * rpb
         self.level_sizes[hid][level + 1] = nblocks * 8
 

@@ -300,6 +300,20 @@ DEFAULT_SOLVER_CFG = {
 }
 
 
+# The benchmark's hierarchy for schwinger128 (bench.py; any L with L/16 a multiple of 4): one more
+# coarsening than the default, so the dense inverse shrinks from 4096^2 to 1024^2 and the 4096-row
+# level is smoothed by 16 polynomial steps instead; built entirely on the GPU (setup_gpu.py).
+# 128^2, one MI355X: 9.8k probe-samples/s against 8.8k for DEFAULT_SOLVER_CFG, same 14 outer iterations.
+TUNED_SOLVER_CFG_128 = {
+    "coarsening": [(4, 8), (2, 8), (2, 8)],
+    "cycle": [(0, 7, 0), (0, 7, 0), (0, 16, 0)],
+    "smoother": "richardson",
+    "restart": 6,
+    "setup": "device",
+    "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,
+}
+
+
 def _site_prolongator(Al, Lf, hd, agg, nvec, tv, fine_level):
     """P for 2-D site aggregates with a chirality split.
 

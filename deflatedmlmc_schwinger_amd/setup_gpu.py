@@ -137,8 +137,13 @@ def level_geometry(Lf, hd, agg, fine_level):
     nbr = np.stack([cs, yc * Lc + (xc + 1) % Lc, yc * Lc + (xc - 1) % Lc,
                     ((yc + 1) % Lc) * Lc + xc, ((yc - 1) % Lc) * Lc + xc], axis=1)
     nbr = np.sort(nbr, axis=1)
-    return {"blk_rows": blk_rows, "G": G, "pcols": pcols, "pmap": pmap, "Lc": Lc, "nbr": nbr,
-            "n_c": nblocks * 8}
+    # visit the row groups sorted by their first coarse column: the groups of one aggregate (spread
+    # over both parity halves of the even-odd order at level 0) become neighbours in time and L2
+    porder = np.argsort(pcols[:, 0], kind="stable")
+    if (porder == np.arange(ng)).all():
+        porder = None
+    return {"blk_rows": blk_rows, "G": G, "pcols": pcols, "pmap": pmap, "porder": porder, "Lc": Lc,
+            "nbr": nbr, "n_c": nblocks * 8}
 
 
 class _EngineOperator:
@@ -199,7 +204,7 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
         with _timed("transfer+galerkin"):
             for lv in range(level, nl - 1):
                 g = geo[lv]
-                eng.setup_transfer(hid, lv, g["blk_rows"], g["G"], g["pcols"], g["pmap"])
+                eng.setup_transfer(hid, lv, g["blk_rows"], g["G"], g["pcols"], g["pmap"], g["porder"])
                 eng.setup_galerkin(hid, lv, g["Lc"], g["nbr"])
 
     def finish():
@@ -232,7 +237,7 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                     "seconds": round(time.time() - t1, 3)})
         g = geo[lvl]
         with _timed("transfer+galerkin"):
-            eng.setup_transfer(hid, lvl, g["blk_rows"], g["G"], g["pcols"], g["pmap"])
+            eng.setup_transfer(hid, lvl, g["blk_rows"], g["G"], g["pcols"], g["pmap"], g["porder"])
             eng.setup_galerkin(hid, lvl, g["Lc"], g["nbr"])
     finish()
     eng.set_solver(int(cfg.get("restart", 24)), hid)

@@ -90,7 +90,8 @@ int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles);
  *   the restricted test vectors as level+1's start.  blk_rows[nblocks*rpb]: level rows (engine row
  *   order) of each block; P's grouped-ELL structure comes from the caller's geometry: group size
  *   G, K columns per group pcols[ngroups*K], and pmap[ngroups*K*G] = index (block*rpb + member)*8 + k
- *   of the value, or -1.
+ *   of the value, or -1; porder[ngroups] (may be NULL): order in which the kernel visits the row
+ *   groups (groups that share coarse columns adjacent).
  * sw_setup_galerkin: A_{level+1} = R A P (multigrid.py:276-280) by 16-colour probing with the
  *   engine's own operator kernels, written straight into MFMA block-row form.  nbr[ncs*5]: the five
  *   sites of each coarse site's 5-point neighbourhood, strictly increasing.
@@ -99,7 +100,7 @@ int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles);
 int sw_setup_testvectors(sw_engine* h, int hid, int level, int nvec, uint64_t seed, int sweeps,
                          double tol, int maxiter, int precond, int32_t* iters_out);
 int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, const int32_t* blk_rows,
-                      int G, int K, const int32_t* pcols, const int64_t* pmap);
+                      int G, int K, const int32_t* pcols, const int64_t* pmap, const int32_t* porder);
 int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* nbr);
 int sw_get_level_dense(sw_engine* h, int hid, int level, double* dense);
 /* Dense inverse of a device-built coarsest operator without leaving the GPU: rocSOLVER LU
@@ -203,6 +204,7 @@ int sw_timers_reset(sw_engine* h);
 #define SW_KCLASS_MFMA_DENSE 11     /* k_bsr_mfma, dense coarsest inverse          */
 #define SW_KCLASS_MFMA_OP 12        /* k_bsr_mfma, block-structured level operator */
 #define SW_KCLASS_STENCIL_SM2 13     /* k_stencil_2step, two fused smoother steps   */
+#define SW_KCLASS_MFMA_OP2 14       /* k_bsr_mfma, level operators below level 1   */
 int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);
 /* Kernel launches issued since the last reset (for launch-bound analysis). */
 int sw_launch_count(sw_engine* h, int64_t* n);

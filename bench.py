@@ -205,7 +205,11 @@ def run(args):
     window0 = ProbeStream(123456).window()
     for e in range(ne):
         engs[e].stream_set(window0)
-    comm = swdist.TorchComm() if td.is_initialized() else swdist.Comm()
+    if td.is_initialized() and os.environ.get("SW_ENGINE_COMM") == "1" and backend == "nccl":
+        # the statistics all-reduce through the engine's own C-ABI collective (sw_allreduce_stats)
+        comm = swdist.EngineComm(engs[0])
+    else:
+        comm = swdist.TorchComm() if td.is_initialized() else swdist.Comm()
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=ne)
 

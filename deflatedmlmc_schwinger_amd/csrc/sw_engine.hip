@@ -24,6 +24,7 @@ using swk::PtrList;
 #define SW_MAXM 32  // engine restart cap (<= SW_MAX_KRYLOV)
 
 static std::string g_create_error;
+static int (*g_rccl_destroy)(void*) = nullptr;   // set when RCCL has been loaded (sw_comm_*)
 
 struct sw_engine;
 static int sw_fail(sw_engine* h, const char* fmt, ...);
@@ -203,6 +204,8 @@ struct sw_engine {
   int64_t launches = 0;
   int* d_notconv = nullptr;
   int* h_notconv = nullptr;  // pinned
+  void* comm = nullptr;      // RCCL communicator (sw_comm_init), one rank per engine
+  double* d_stats = nullptr; // [4] all-reduce buffer
 };
 
 static int sw_fail(sw_engine* h, const char* fmt, ...) {
@@ -1143,6 +1146,7 @@ int sw_destroy(sw_engine* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   for (auto& a : h->allocs) (void)hipFree(a.first);
   for (auto& r : h->recs) {
     (void)hipEventDestroy(r.e0);
@@ -2331,6 +2335,85 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
     KLAUNCH_CHECK();
   }
   SWCHK(stream_sync(h));
+  return 0;
+}
+
+// ---- the one collective of the path: trace-sum / variance statistics over the ranks (RCCL over xGMI)
+namespace {
+struct RcclUid {
+  char internal[128];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*get_uid)(RcclUid*) = nullptr;
+  int (*init_rank)(void**, int, RcclUid, int) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*destroy)(void*) = nullptr;
+  bool tried = false, ok = false;
+};
+Rccl g_rccl;
+bool load_rccl() {
+  if (g_rccl.tried) return g_rccl.ok;
+  g_rccl.tried = true;
+  g_rccl.lib = dlopen("librccl.so", RTLD_NOW);
+  if (!g_rccl.lib) g_rccl.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW);
+  if (!g_rccl.lib) return false;
+  g_rccl.get_uid = (int (*)(RcclUid*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.init_rank = (int (*)(void**, int, RcclUid, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(
+      g_rccl.lib, "ncclAllReduce");
+  g_rccl.destroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.ok = g_rccl.get_uid && g_rccl.init_rank && g_rccl.all_reduce && g_rccl.destroy;
+  if (g_rccl.ok) g_rccl_destroy = g_rccl.destroy;
+  return g_rccl.ok;
+}
+}  // namespace
+
+int sw_comm_unique_id(char id[128]) {
+  if (!id || !load_rccl()) return 1;
+  RcclUid u;
+  if (g_rccl.get_uid(&u) != 0) return 1;
+  std::memcpy(id, u.internal, 128);
+  return 0;
+}
+
+int sw_comm_init(sw_engine* h, int nranks, int rank, const char id[128]) {
+  if (!h) return 1;
+  if (!id || nranks < 1 || rank < 0 || rank >= nranks) return sw_fail(h, "bad arguments");
+  if (!load_rccl()) return sw_fail(h, "RCCL could not be loaded (%s)", dlerror());
+  HIPCHK(hipSetDevice(h->device));
+  if (h->comm) {
+    g_rccl.destroy(h->comm);
+    h->comm = nullptr;
+  }
+  RcclUid u;
+  std::memcpy(u.internal, id, 128);
+  void* c = nullptr;
+  const int rc = g_rccl.init_rank(&c, nranks, u, rank);
+  if (rc != 0 || !c) return sw_fail(h, "ncclCommInitRank failed (status %d)", rc);
+  h->comm = c;
+  if (!h->d_stats) SWCHK(dev_realloc(h, &h->d_stats, (size_t)4));
+  return 0;
+}
+
+int sw_allreduce_stats(sw_engine* h, double stats[4]) {
+  if (!h) return 1;
+  if (!stats) return sw_fail(h, "null statistics");
+  if (!h->comm) return sw_fail(h, "no communicator (sw_comm_init)");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_stats, stats, 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int rc = g_rccl.all_reduce(h->d_stats, h->d_stats, 4, /*ncclFloat64*/ 8, /*ncclSum*/ 0,
+                                   h->comm, h->stream);
+  if (rc != 0) return sw_fail(h, "ncclAllReduce failed (status %d)", rc);
+  HIPCHK(hipMemcpyAsync(stats, h->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int sw_comm_destroy(sw_engine* h) {
+  if (!h) return 1;
+  if (h->comm && g_rccl.ok) g_rccl.destroy(h->comm);
+  h->comm = nullptr;
   return 0;
 }
 

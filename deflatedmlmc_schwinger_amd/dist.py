@@ -170,3 +170,19 @@ def mean_and_population_std(stats):
     mean = complex(s_re, s_im) / n
     var = max(s_abs2 / n - abs(mean) ** 2, 0.0)
     return mean, float(np.sqrt(var))
+
+
+class EngineComm(TorchComm):
+    """TorchComm whose statistics all-reduce goes through the engine's own C-ABI collective
+    (`sw_allreduce_stats`: RCCL ncclAllReduce on the engine's stream).  The RCCL unique id travels
+    over the existing torch.distributed group (any transport would do)."""
+
+    def __init__(self, engine, device=None):
+        super().__init__(device)
+        box = [engine.comm_unique_id() if self.rank == 0 else None]
+        self._td.broadcast_object_list(box, src=0)
+        engine.comm_init(self.world, self.rank, box[0])
+        self._engine = engine
+
+    def allreduce_stats(self, stats):
+        return self._engine.allreduce_stats(stats)

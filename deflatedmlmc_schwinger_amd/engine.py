@@ -90,6 +90,10 @@ def load_library():
     sig("sw_probes_upload_slot", i32, vp, i32, i32, i32, vp)
     sig("sw_probes_select", i32, vp, i32)
     sig("sw_kernel_stats", i32, vp, i32, P(dbl), P(i64))
+    sig("sw_comm_unique_id", i32, vp)
+    sig("sw_comm_init", i32, vp, i32, i32, vp)
+    sig("sw_allreduce_stats", i32, vp, vp)
+    sig("sw_comm_destroy", i32, vp)
     sig("sw_hutch_run", i32, vp, i32, i32, dbl, i32)
     sig("sw_sync", i32, vp)
     sig("sw_hutch_fetch", i32, vp, vp, vp)
@@ -125,6 +129,7 @@ EXPORTED_SYMBOLS = (
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
+    "sw_comm_unique_id", "sw_comm_init", "sw_allreduce_stats", "sw_comm_destroy",
     "sw_bench_dirac", "sw_set_profiling", "sw_timers", "sw_timers_reset", "sw_launch_count",
     "sw_mt_create", "sw_mt_destroy", "sw_mt_skip", "sw_mt_raw", "sw_mt_rademacher",
     "sw_mt_z4", "sw_mt_from_state", "sw_mt_get_state", "sw_mt_window", "sw_mt_jump",
@@ -449,6 +454,28 @@ class Engine:
         iters = np.zeros(2 * nb, dtype=np.int32)
         self._chk(self._lib.sw_hutch_fetch(self._h, _ptr(ests), _ptr(iters)), "sw_hutch_fetch")
         return ests, iters[:nb].copy(), iters[nb:].copy()
+
+    # -- the collective behind the C ABI (RCCL) -----------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        if load_library().sw_comm_unique_id(buf) != 0:
+            raise EngineError("sw_comm_unique_id failed (RCCL not loadable)")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, uid):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._chk(self._lib.sw_comm_init(self._h, int(nranks), int(rank), buf), "sw_comm_init")
+
+    def allreduce_stats(self, stats):
+        a = np.ascontiguousarray(stats, dtype=np.float64).copy()
+        if a.size != 4:
+            raise EngineError("four statistics expected")
+        self._chk(self._lib.sw_allreduce_stats(self._h, _ptr(a)), "sw_allreduce_stats")
+        return a
+
+    def comm_destroy(self):
+        self._chk(self._lib.sw_comm_destroy(self._h), "sw_comm_destroy")
 
     # -- measurement -----------------------------------------------------------------------
     def bench_dirac(self, hid, level, nb, reps):

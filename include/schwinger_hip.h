@@ -185,6 +185,17 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter);
 int sw_sync(sw_engine* h);
 int sw_hutch_fetch(sw_engine* h, double* ests, int32_t* iters);
 
+/* ---- multi-GPU: the one collective of the path ------------------------------------ */
+/* One process per GPU, one engine per process; the probe loop shards by probe and needs a single
+ * small reduction per round: {sum Re e, sum Im e, sum |e|^2, n} (population variance as
+ * stoch_trace.py:143-145).  RCCL (ncclAllReduce over xGMI) behind the C ABI, loaded on first use:
+ * rank 0 calls sw_comm_unique_id and hands the 128 bytes to the other ranks by any means; every
+ * rank calls sw_comm_init; sw_allreduce_stats sums the four doubles in place over all ranks. */
+int sw_comm_unique_id(char id[128]);
+int sw_comm_init(sw_engine* h, int nranks, int rank, const char id[128]);
+int sw_allreduce_stats(sw_engine* h, double stats[4]);
+int sw_comm_destroy(sw_engine* h);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* Timed stencil loop for the roofline figure: `reps` applications of the level-0 operator of
  * hierarchy hid on nb resident right-hand sides, HIP events on the engine stream.

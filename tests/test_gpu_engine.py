@@ -794,3 +794,23 @@ def test_device_side_setup_builds_an_equivalent_hierarchy(p128):
                 assert max(entry["gmres_iterations"]) < 64            # converged, not capped
     finally:
         p.mg.upload_solver_hierarchy(None)
+
+
+def test_c_abi_collective_single_rank(p16):
+    """sw_comm_* / sw_allreduce_stats (RCCL behind the C ABI): on the one GPU of the
+    test box a one-rank communicator; the reduction must return the statistics unchanged and the
+    derived mean / population deviation must be those of stoch_trace.py:143-145."""
+    from deflatedmlmc_schwinger_amd import dist
+    from deflatedmlmc_schwinger_amd.engine import Engine
+    uid = Engine.comm_unique_id()
+    assert len(uid) == 128
+    p16.eng.comm_init(1, 0, uid)
+    e = _rand(37, 9)
+    stats = dist.local_stats(e)
+    out = p16.eng.allreduce_stats(stats)
+    assert np.array_equal(out, stats)
+    mean, std = dist.mean_and_population_std(out)
+    assert abs(mean - e.mean()) < 1e-13 and abs(std - np.sqrt(np.mean(np.abs(e - e.mean()) ** 2))) < 1e-12
+    p16.eng.comm_destroy()
+    with pytest.raises(Exception, match="no communicator"):
+        p16.eng.allreduce_stats(stats)

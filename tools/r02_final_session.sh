@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-2 evidence in one GPU call: profile of the default bench, the other workloads, synthetic lattices.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+bash tools/profile_round.sh r02 > gpurun_out/r02_profile.log 2>&1
+timeout -k 10 400 python3 bench.py --workload config2 --steps 4 --warmup 1 --no-large-stencil > gpurun_out/r02_bench_config2.json 2> gpurun_out/r02_bench_config2.err
+timeout -k 10 300 python3 bench.py --workload mlmc --steps 6 --warmup 2 --no-large-stencil > gpurun_out/r02_bench_mlmc.json 2> gpurun_out/r02_bench_mlmc.err
+for L in 512 1024; do
+  timeout -k 10 400 python3 bench.py --workload synthetic --lattice $L --nb 64 --streams 1 --steps 3 --warmup 1 > gpurun_out/r02_synth$L.json 2> gpurun_out/r02_synth$L.err
+done
+python3 - <<'PY'
+import json
+for f in ("r02/bench", "r02_bench_config2", "r02_bench_mlmc", "r02_synth512", "r02_synth1024"):
+    d = json.load(open("gpurun_out/%s.json" % f))
+    print(f, round(d["value"], 1), d["config"]["outer_iterations_max"], d["roofline"]["kernel"], round(d["roofline"]["frac"], 3))
+PY

@@ -15,7 +15,8 @@ def short(name):
 
 def main(out):
     lines = []
-    stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]      # gpurun merges runs into one tree
+    stats = newest(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -28,14 +29,22 @@ def main(out):
         lines.append("total kernel time %.1f ms" % (tot / 1e6))
     pmc = {}
     for key, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(out, key, "**", "*counter_collection.csv"), recursive=True)
+        files = newest(glob.glob(os.path.join(out, key, "**", "*counter_collection.csv"), recursive=True))
         if not files:
             continue
+        # per kernel, only the launches of its LARGEST grid size: the profiled process also
+        # runs the device-side setup, whose launches of the same kernels work on 64 columns
+        rows = [r for r in csv.DictReader(open(files[0])) if r.get("Counter_Name") == counter]
+        grids = {}
+        for r in rows:
+            g = grids.setdefault(short(r["Kernel_Name"]), {})
+            g[r["Grid_Size"]] = g.get(r["Grid_Size"], 0) + 1
+        main_grid = {k: max(g, key=lambda q: int(q)) for k, g in grids.items()}
         acc = {}
-        for r in csv.DictReader(open(files[0])):
-            if r.get("Counter_Name") != counter:
-                continue
+        for r in rows:
             k = short(r["Kernel_Name"])
+            if r["Grid_Size"] != main_grid[k]:
+                continue
             a = acc.setdefault(k, [0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -43,7 +52,8 @@ def main(out):
     summary = {}
     if pmc:
         lines.append("")
-        lines.append("PMC passes (separate runs): per-launch averages; FETCH_SIZE/WRITE_SIZE are in KiB;")
+        lines.append("PMC passes (separate runs): per-launch averages over the launches of each kernel's largest")
+        lines.append("grid size (the solve's; the device-side setup launches the same kernels on 64 columns); KiB counters;")
         lines.append("FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md, HBM; the")
         lines.append("factor 2 was re-measured for this engine's three read shapes, profiles/r02_pmc_calibration.txt)")
         names = sorted(set(list(pmc.get("FETCH_SIZE", {})) + list(pmc.get("WRITE_SIZE", {}))))
@@ -57,6 +67,7 @@ def main(out):
             tags = {"k_stencil<0,": "k_stencil<0>", "k_stencil<1,": "k_stencil<1>",
                     "k_stencil<2,": "k_stencil<2>",
                     "k_bsr_mfma<0, 4, false": "k_bsr_mfma(dense coarsest)",
+                    "k_bsr_mfma<0, 2, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<3, 4, true": "k_bsr_mfma(level-1 operator)",
                     "k_bsr_mfma<3, 4, false": "k_bsr_mfma(level-1 operator)",
                     "k_bsr_mfma<3, 2, true": "k_bsr_mfma(level-2 operator)",

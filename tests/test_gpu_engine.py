@@ -814,3 +814,61 @@ def test_c_abi_collective_single_rank(p16):
     p16.eng.comm_destroy()
     with pytest.raises(Exception, match="no communicator"):
         p16.eng.allreduce_stats(stats)
+
+
+def test_mixed_convergence_after_a_stale_sync_hint(p128):
+    """ADVICE r1 (lazy sync): after a batch that left a large iteration hint, a batch mixing a
+    right-hand side that converges at once (b = A P y: the coarse correction is exact for it), a
+    zero right-hand side and ordinary ones.  Converged probes are frozen (no division by a
+    round-off h_{j+1,j}); every solution must meet the TRUE residual bound and equal LU."""
+    p = p128
+    n = p.A.shape[0]
+    hard = _rand((64, n), 123)
+    _, its_hard, _ = p.mg.solve_batch(0, hard, 1e-12)           # leaves sync_hint ~ 14
+    assert int(np.max(its_hard)) >= 8
+    P0, P1 = p.mg.solver_hier["P"][0], p.mg.solver_hier["P"][1]
+    rng = np.random.default_rng(77)
+    y = rng.standard_normal(P1.shape[1]) + 1j * rng.standard_normal(P1.shape[1])
+    B = np.zeros((5, n), dtype=np.complex128)
+    # x = P0 P1 y lies in the range of both prolongators: every coarse correction of the cycle is
+    # exact for b = A x (dense inverse at the bottom), so these two converge at once
+    B[0] = p.A @ (P0 @ (P1 @ y))
+    B[1] = _rand((n,), 5)
+    B[3] = 1e-9 * _rand((n,), 6)                                # tiny but non-zero
+    B[4] = p.A @ (P0 @ (P1 @ y[::-1].copy()))
+    X, its, relres = p.mg.solve_batch(0, B, 1e-12)              # B[2] = 0
+    assert its[2] == 0 and np.all(X[2] == 0)
+    assert its[0] <= 3 and its[4] <= 3 and its[1] >= its[0] + 4
+    lu = p.lu_solver(0)
+    for k in (0, 1, 3, 4):
+        r = B[k] - p.A @ X[k]
+        assert np.linalg.norm(r) < 2e-12 * np.linalg.norm(B[k])
+        assert _relerr(X[k], lu(B[k])) < 1e-9
+        assert relres[k] < 1e-12
+
+
+def test_redefining_hierarchy_zero_resets_probe_state():
+    """sw_hier_begin(hid 0) drops everything sized by the previous definition
+    (deflation vectors, permutations, probe slots and workspace), so a handle can move from a
+    larger lattice to a smaller one and back."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    from deflatedmlmc_schwinger_amd.engine import Engine
+    eng = Engine(0)
+    for L in (32, 8, 16):
+        A = matrix.synthetic_matrix(L, 0.2, 0.3, 5)
+        lat = hierarchy.detect_lattice(A)
+        eng.hier_begin(REF_HID, 1)
+        eng.set_lattice(REF_HID, lat[0], lat[1], lat[2], lat[3])
+        eng.hier_end(REF_HID)
+        eng.set_solver(16, REF_HID)
+        n = A.shape[0]
+        U, _ = np.linalg.qr(_rand((n, 3), L))
+        eng.set_deflation(U)
+        np.random.seed(L)
+        probes = utils.draw_probes(5, n)
+        ests, _, _ = eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+        lu = rp.LUSolver(A)
+        for k in range(5):
+            ref = rp.hutch_probe(probes[k].astype(np.complex128), lu, U, None)
+            assert abs(ests[k] - ref) < 1e-10 * max(1.0, abs(ref))
+    eng.close()

@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nb", type=int, default=256, help="probes per engine stream per step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "3")),
                     help="concurrent probe batches (engine handles / HIP streams) per GPU")
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),

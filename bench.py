@@ -292,7 +292,7 @@ def run(args):
     kstats = {name: eng.kernel_stats(cls) for name, cls in
               (("k_stencil<0>", 8), ("k_stencil<1>", 9), ("k_stencil<2>", 10),
                ("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
-               ("k_bsr_mfma(level-2 operator)", 14))}
+               ("k_bsr_mfma(level-2 operator)", 14), ("k_schur_step", 15))}
     buckets = eng.timers()
     launches = eng.launch_count()
     eng.set_profiling(False)
@@ -311,6 +311,8 @@ def run(args):
             "k_stencil<0>": ("hbm", V * (64.0 * nbp + 32.0)),
             "k_stencil<1>": ("hbm", V * (96.0 * nbp + 32.0)),              # + read of B
             "k_stencil<2>": ("hbm", V * (96.0 * nbp + 32.0)),              # fused smoother step
+            # even-odd smoother step / hop: three HALF-vector passes (x_e, b'_e in, x_e out) + links
+            "k_schur_step": ("hbm", 0.5 * V * (96.0 * nbp + 64.0)),
             "k_bsr_mfma(dense coarsest)": ("mfma", 8.0 * nc * nc * nbp),
             "k_bsr_mfma(level-1 operator)": ("mfma", 8.0 * levels[1] * 80.0 * nbp
                                              if len(levels) > 2 else 0.0),
@@ -349,7 +351,7 @@ def run(args):
                               "launches_in_step": cnt, "step_ms": ms_tot})
         rooflines.sort(key=lambda r: -r["step_ms"])
         dominant = rooflines[0] if rooflines else None
-        stencil = max((r for r in rooflines if r["kernel"].startswith("k_stencil")),
+        stencil = max((r for r in rooflines if r["kernel"].startswith(("k_stencil", "k_schur"))),
                       key=lambda r: r["step_ms"], default=None)
         bytes0 = algo["k_stencil<0>"][1]
         out = {

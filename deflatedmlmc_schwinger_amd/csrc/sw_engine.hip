@@ -50,6 +50,7 @@ enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER
                 T_MFMA_OP,      // k_bsr_mfma on a block-structured level operator
                 T_STENCIL_SM2,  // k_stencil_2step: two fused smoother steps
                 T_MFMA_OP2,     // k_bsr_mfma on level operators below level 1 of the solver hierarchy
+                T_SCHUR,        // k_schur_step / k_eo_hop: even-odd smoother of the stencil level
                 T_NCAT };
 // classes >= T_STENCIL are folded into the mvm / coarsest buckets by sw_timers and reported
 // separately by sw_kernel_stats
@@ -91,6 +92,8 @@ struct Level {
   // fixed-polynomial (Richardson) smoother: weights 1/theta_k; empty -> adaptive MR steps
   std::vector<std::complex<double>> w_pre, w_post;
   bool rich = false;
+  // even-odd post-smoother of the stencil level: Richardson weights for the Schur complement S
+  std::vector<std::complex<double>> w_eo;
   std::vector<int> h_rowmap;  // natural -> internal (empty: identity)
   int* rowmap = nullptr;
   // per-level cycle workspace, [n][nbp]
@@ -898,6 +901,51 @@ static int coarse_correction(sw_engine* h, Hier& H, int l, int nbp) {
   return vcycle(h, H, l + 1, lc.b, lc.x, nbp);
 }
 
+// Even-odd post-smoothing of the stencil level (k_schur_step): on entry `start` holds the iterate
+// after the coarse correction (only its even half is used), on exit Xout the smoothed iterate.
+// `start` and `other` are the ping-pong pair chosen by the caller so that the last step lands in Xout.
+static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx* other, cplx* Xout,
+                     int nbp) {
+  swk::StencilArgs a;
+  a.L = lv.L;
+  a.Vh = lv.L * lv.L / 2;
+  a.diag = 4.0 + lv.mass;
+  a.U1 = lv.U1;
+  a.U2 = lv.U2;
+  a.nbp = nbp;
+  a.nt_store = 0;
+  a.tile_w = lv.L;
+  a.w = cplx{0.0, 0.0};
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  const double di = 1.0 / a.diag;
+  cplx* bp = lv.r;   // b'_e lives in the even half of the level's residual buffer
+  {
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0, di,
+                       bpc);
+    KLAUNCH_CHECK();
+  }
+  cplx* cur = start;
+  cplx* nxt = other;
+  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur,
+                       (const cplx*)bp, nxt, a, bpc);
+    KLAUNCH_CHECK();
+    std::swap(cur, nxt);
+  }
+  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
+  {
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, (const cplx*)Xout,
+                       Xout, a, di, di, bpc);
+    KLAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // cycle with the fixed-polynomial smoother (weights set by sw_set_smoother)
 static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
   Level& lv = H.lv[l];
@@ -915,6 +963,14 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
     SWCHK(launch_ell(h, lv.R, 0, Bin, nullptr, lc.b, nbp, T_R));
   }
   SWCHK(coarse_correction(h, H, l, nbp));
+  if (lv.stencil && !lv.w_eo.empty() && !xpre) {
+    // even-odd post-smoother: prolongate into the buffer from which nu steps end in Xout
+    const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+    cplx* start = odd_steps ? lv.t : Xout;
+    cplx* other = odd_steps ? Xout : lv.t;
+    SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, start, nbp, T_P));
+    return eo_smooth(h, lv, Bin, start, other, Xout, nbp);
+  }
   // place the prolongated iterate so that the ping-pong launches of the post-smoother end in Xout
   // (pairs of steps are one launch on the stencil level)
   const bool fused = lv.stencil && h->fuse_smoother && lv.L >= 4;
@@ -1672,6 +1728,17 @@ int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles) {
   Level& lv = h->hier[hid].lv[level];
   lv.gm_m = m;
   lv.gm_cycles = m > 0 ? cycles : 0;
+  return 0;
+}
+
+int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const double* w_post) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (n_post < 0 || n_post > 64 || (n_post > 0 && !w_post)) return sw_fail(h, "sw_set_eo_smoother: bad arguments");
+  Level& lv = h->hier[hid].lv[level];
+  if (n_post > 0 && !lv.stencil) return sw_fail(h, "the even-odd smoother is defined for the stencil level");
+  lv.w_eo.clear();
+  for (int i = 0; i < n_post; ++i) lv.w_eo.emplace_back(w_post[2 * i], w_post[2 * i + 1]);
+  if (n_post > 0) lv.rich = true;     // the cycle with fixed weights (vcycle_rich)
   return 0;
 }
 
@@ -2516,7 +2583,7 @@ int sw_timers(sw_engine* h, double t[8]) {
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
   t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP] +
-              h->tacc[T_STENCIL_SM2] + h->tacc[T_MFMA_OP2];
+              h->tacc[T_STENCIL_SM2] + h->tacc[T_MFMA_OP2] + h->tacc[T_SCHUR];
   t[T_COARSEST] += h->tacc[T_MFMA_DENSE];
   return 0;
 }

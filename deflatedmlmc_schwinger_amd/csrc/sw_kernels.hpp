@@ -364,6 +364,152 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step_lds(const cplx* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// Even-odd (Schur-complement) smoothing of the stencil level.  With the rows in even-odd order,
+//   A = [ D  -H_eo ; -H_oe  D ],  D = 4 + m,   S = D - H_eo H_oe / D   (even sites only)
+// and A^-1 b follows from  b'_e = b_e + H_eo b_o / D,  S x_e = b'_e,  x_o = (b_o + H_oe x_e) / D.
+// The post-smoother iterates x_e <- x_e + w_k (b'_e - S x_e) on HALF vectors and then sets x_o
+// exactly: errors on the odd sites and the operator's upper spectrum are gone after one step,
+// and S is four times better conditioned than A.  The two hops of S are ONE kernel: the
+// back-tracking paths vanish identically ((1 -+ s_mu)(1 +- s_mu) = 0), leaving the 8 even sites
+// at lattice distance 2 (16 row loads + x_e, b'_e: 20 per output site, L2-served), and the HBM
+// traffic of a step is 3 half-vector passes = 201 MB instead of 403 MB (128^2, 256 probes).
+// ------------------------------------------------------------------------------------------
+// contribution of one hop to a 2-spinor: dir 0:+x (1-s1) u psi, 1:-x (1+s1) conj(u) psi,
+// 2:+y (1-s2) u psi, 3:-y (1+s2) conj(u) psi   (u = the link the hop runs along)
+template <int DIR>
+__device__ __forceinline__ void hop_acc(Site2& acc, cplx u, Site2 psi) {
+  if (DIR == 0) {
+    const cplx t = cmul(u, csub(psi.s0, psi.s1));
+    acc.s0 = cadd(acc.s0, t);
+    acc.s1 = csub(acc.s1, t);
+  } else if (DIR == 1) {
+    const cplx t = cmulc(u, cadd(psi.s0, psi.s1));
+    acc.s0 = cadd(acc.s0, t);
+    acc.s1 = cadd(acc.s1, t);
+  } else if (DIR == 2) {
+    const cplx t = cmul(u, cadd(psi.s0, cmuli(psi.s1)));
+    acc.s0 = cadd(acc.s0, t);
+    acc.s1 = csub(acc.s1, cmuli(t));
+  } else {
+    const cplx t = cmulc(u, csub(psi.s0, cmuli(psi.s1)));
+    acc.s0 = cadd(acc.s0, t);
+    acc.s1 = cadd(acc.s1, cmuli(t));
+  }
+}
+
+__device__ __forceinline__ int wrap_p(int v, int L) { return (v + 1 == L) ? 0 : v + 1; }
+__device__ __forceinline__ int wrap_m(int v, int L) { return (v == 0) ? L - 1 : v - 1; }
+
+// site (x, y) of parity q from its index sh in [0, V/2)
+__device__ __forceinline__ void eo_site(int sh, int q, int L, int& x, int& y) {
+  const int hl = L >> 1;
+  y = sh / hl;
+  x = 2 * (sh - y * hl) + ((q + y) & 1);
+}
+
+// out(n) = alpha * Uv(n) + beta * (H src)(n)  on the sites n of parity Q; src on the other parity.
+//   Q = 0, Uv = src = B, alpha = 1, beta = 1/D :  b'_e = b_e + H_eo b_o / D
+//   Q = 1, Uv = B, src = X, alpha = beta = 1/D:  x_o  = (b_o + H_oe x_e) / D
+template <int Q>
+__global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const cplx* __restrict__ Uv,
+                                                     const cplx* __restrict__ src,
+                                                     cplx* __restrict__ out, StencilArgs a,
+                                                     double alpha, double beta,
+                                                     int blocks_per_chunk) {
+  const int bb = xcd_remap(blockIdx.x, gridDim.x);
+  const int chunk = bb / blocks_per_chunk;
+  const int sg = bb % blocks_per_chunk;
+  const int lane = threadIdx.x & 63;
+  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
+  const size_t col = (size_t)chunk * 64 + lane;
+  const int sh = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (sh >= Vh) return;
+  int x, y;
+  eo_site(sh, Q, L, x, y);
+  const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
+  const cplx* S = src + col;
+  Site2 acc;
+  acc.s0 = cmake(0.0, 0.0);
+  acc.s1 = acc.s0;
+  hop_acc<0>(acc, a.U1[y * L + x], ld_site(S, xp, y, L, Vh, nbp));
+  hop_acc<1>(acc, a.U1[y * L + xm], ld_site(S, xm, y, L, Vh, nbp));
+  hop_acc<2>(acc, a.U2[y * L + x], ld_site(S, x, yp, L, Vh, nbp));
+  hop_acc<3>(acc, a.U2[ym * L + x], ld_site(S, x, ym, L, Vh, nbp));
+  const size_t r = eo_row(x, y, L, Vh);
+  const cplx u0 = Uv[r * nbp + col], u1 = Uv[(r + 1) * nbp + col];
+  out[r * nbp + col] = cmake(fma(alpha, u0.x, beta * acc.s0.x), fma(alpha, u0.y, beta * acc.s0.y));
+  out[(r + 1) * nbp + col] = cmake(fma(alpha, u1.x, beta * acc.s1.x), fma(alpha, u1.y, beta * acc.s1.y));
+}
+
+// Y_e = X_e + w (Bp_e - S X_e),  S = D - H_eo H_oe / D : both hops in one kernel (even sites only)
+__global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const cplx* __restrict__ X,
+                                                         const cplx* __restrict__ Bp,
+                                                         cplx* __restrict__ Y, StencilArgs a,
+                                                         int blocks_per_chunk) {
+  const int bb = xcd_remap(blockIdx.x, gridDim.x);
+  const int chunk = bb / blocks_per_chunk;
+  const int sg = bb % blocks_per_chunk;
+  const int lane = threadIdx.x & 63;
+  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
+  const size_t col = (size_t)chunk * 64 + lane;
+  const int sh = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (sh >= Vh) return;
+  int x, y;
+  eo_site(sh, 0, L, x, y);
+  const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
+  const int xpp = wrap_p(xp, L), xmm = wrap_m(xm, L), ypp = wrap_p(yp, L), ymm = wrap_m(ym, L);
+  const cplx* Xc = X + col;
+  // the eight even sites at distance 2
+  const Site2 e20 = ld_site(Xc, xpp, y, L, Vh, nbp), em20 = ld_site(Xc, xmm, y, L, Vh, nbp);
+  const Site2 e02 = ld_site(Xc, x, ypp, L, Vh, nbp), e0m2 = ld_site(Xc, x, ymm, L, Vh, nbp);
+  const Site2 ePP = ld_site(Xc, xp, yp, L, Vh, nbp), ePM = ld_site(Xc, xp, ym, L, Vh, nbp);
+  const Site2 eMP = ld_site(Xc, xm, yp, L, Vh, nbp), eMM = ld_site(Xc, xm, ym, L, Vh, nbp);
+  const cplx* U1 = a.U1;
+  const cplx* U2 = a.U2;
+#define SW_U1(xx, yy) U1[(yy) * L + (xx)]
+#define SW_U2(xx, yy) U2[(yy) * L + (xx)]
+  Site2 z;
+  z.s0 = cmake(0.0, 0.0);
+  z.s1 = z.s0;
+  // t(o) = sum over the hops into the odd neighbour o that do not come from n; then the hop o -> n
+  Site2 t = z;                                          // o = n + x
+  hop_acc<0>(t, SW_U1(xp, y), e20);
+  hop_acc<2>(t, SW_U2(xp, y), ePP);
+  hop_acc<3>(t, SW_U2(xp, ym), ePM);
+  Site2 acc = z;
+  hop_acc<0>(acc, SW_U1(x, y), t);
+  t = z;                                                // o = n - x
+  hop_acc<1>(t, SW_U1(xmm, y), em20);
+  hop_acc<2>(t, SW_U2(xm, y), eMP);
+  hop_acc<3>(t, SW_U2(xm, ym), eMM);
+  hop_acc<1>(acc, SW_U1(xm, y), t);
+  t = z;                                                // o = n + y
+  hop_acc<2>(t, SW_U2(x, yp), e02);
+  hop_acc<0>(t, SW_U1(x, yp), ePP);
+  hop_acc<1>(t, SW_U1(xm, yp), eMP);
+  hop_acc<2>(acc, SW_U2(x, y), t);
+  t = z;                                                // o = n - y
+  hop_acc<3>(t, SW_U2(x, ymm), e0m2);
+  hop_acc<0>(t, SW_U1(x, ym), ePM);
+  hop_acc<1>(t, SW_U1(xm, ym), eMM);
+  hop_acc<3>(acc, SW_U2(x, ym), t);
+#undef SW_U1
+#undef SW_U2
+  const size_t r = eo_row(x, y, L, Vh);
+  const double d = a.diag, di = 1.0 / a.diag;
+  const cplx c0 = Xc[r * nbp], c1 = Xc[(r + 1) * nbp];
+  const cplx q0 = Bp[r * nbp + col], q1 = Bp[(r + 1) * nbp + col];
+  // residual of S: b' - (D x - acc / D)
+  const cplx r0 = cmake(q0.x - d * c0.x + di * acc.s0.x, q0.y - d * c0.y + di * acc.s0.y);
+  const cplx r1 = cmake(q1.x - d * c1.x + di * acc.s1.x, q1.y - d * c1.y + di * acc.s1.y);
+  cplx o0 = c0, o1 = c1;
+  cfma(o0, a.w, r0);
+  cfma(o1, a.w, r1);
+  Y[r * nbp + col] = o0;
+  Y[(r + 1) * nbp + col] = o1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Grouped-ELL operator: coarse operators A_l, prolongators P_l, restrictors R_l = P_l^H, the
 // dense coarsest inverse and the MLMC rhs maps.  G consecutive rows share one list of K column
 // indices (the dense-block structure of SURVEY 3.4); one wave = one row group x 64 probes, each

@@ -259,16 +259,20 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
 # ---------------------------------------------------------------------------------------
 # solver hierarchy (level-0 preconditioner only)
 # ---------------------------------------------------------------------------------------
-def smoother_weights(A, degree, seed=2024):
+def smoother_weights(A, degree, seed=2024, project=None):
     """Weights 1/theta_k of a degree-`degree` fixed polynomial smoother for A: theta_k are the
     roots of the GMRES(degree) residual polynomial (harmonic Ritz values) of a random complex
-    right-hand side, Leja-ordered for stability.  x <- x + w_k (b - A x), k = 0..degree-1."""
+    right-hand side, Leja-ordered for stability.  x <- x + w_k (b - A x), k = 0..degree-1.
+    `project` (optional) maps the random start vector to the part of it the smoother is for (e.g.
+    v - P R v: what the coarse correction leaves), so the polynomial spends its degree there."""
     import scipy.linalg as sla
     if degree <= 0:
         return np.zeros(0, dtype=np.complex128)
     n = A.shape[0]
     rng = np.random.default_rng(seed)
     b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    if project is not None:
+        b = np.asarray(project(b), dtype=np.complex128)
     V = [b / np.linalg.norm(b)]
     H = np.zeros((degree + 1, degree), dtype=np.complex128)
     for j in range(degree):
@@ -288,6 +292,24 @@ def smoother_weights(A, degree, seed=2024):
     return 1.0 / np.array(ordered, dtype=np.complex128)
 
 
+def schur_complement(A, L):
+    """Even-odd split of a level-0 operator in the reference order idx(s,x,y) = s L^2 + y L + x:
+    returns (S, E, O, D) with S = D - A_eo A_oe / D on the even sites E (both spins), O the odd
+    ones and D the constant diagonal (A_ee = A_oo = D I for the Wilson stencil)."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    V = L * L
+    idx = np.arange(n)
+    site = idx % V
+    even = (((site % L) + (site // L)) & 1) == 0
+    E, O = idx[even], idx[~even]
+    D = A.diagonal()[0]
+    Aeo = A[E][:, O]
+    Aoe = A[O][:, E]
+    S = sp.identity(E.size, dtype=np.complex128, format="csr") * D - (Aeo @ Aoe) / D
+    return sp.csr_matrix(S), E, O, D
+
+
 DEFAULT_SOLVER_CFG = {
     # (aggregate edge in sites of the level above, test vectors per chirality) per coarsening
     "coarsening": [(4, 8), (2, 8)],
@@ -303,15 +325,19 @@ DEFAULT_SOLVER_CFG = {
 # The benchmark's hierarchy for schwinger128 (bench.py; any L with L/16 a multiple of 4): one more
 # coarsening than the default, so the dense inverse shrinks from 4096^2 to 1024^2 and the 4096-row
 # level is smoothed by 16 polynomial steps instead; built entirely on the GPU (setup_gpu.py).
-# 128^2, one MI355X: 9.8k probe-samples/s against 8.8k for DEFAULT_SOLVER_CFG, same 14 outer iterations.
+# 128^2, one MI355X (3 streams): 11.6k probe-samples/s, 13 outer iterations (9.9k / 14 without the
+# even-odd smoother; 8.8k for DEFAULT_SOLVER_CFG with 2 streams).
 TUNED_SOLVER_CFG_128 = {
     "coarsening": [(4, 8), (2, 8), (2, 8)],
-    "cycle": [(0, 7, 0), (0, 7, 0), (0, 16, 0)],
+    "cycle": [(0, 6, 0), (0, 7, 0), (0, 16, 0)],
     "smoother": "richardson",
+    "eo_smoother": True,        # level 0 smoothed on the even-odd Schur complement (6 half-vector steps)
     "restart": 6,
     "setup": "device",
     "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,
 }
+# cfg["eo_smoother"] = True: the post-smoothing steps of level 0 (cycle[0][1] of them) run on the
+# even-odd Schur complement (sw_set_eo_smoother) instead of the full operator.
 
 
 def _site_prolongator(Al, Lf, hd, agg, nvec, tv, fine_level):

@@ -258,6 +258,10 @@ class MG:
                                             _hier.smoother_weights(sh["A"][i], cyc[1])))
             else:
                 self.solver_weights.append(None)
+        self.solver_weights_eo = None
+        if cfg.get("eo_smoother") and cfg.get("smoother", "richardson") == "richardson":
+            S, _, _, _ = _hier.schur_complement(sh["A"][0], L)
+            self.solver_weights_eo = _hier.smoother_weights(S, cfg["cycle"][0][1])
         for eng in self.engines:
             eng.hier_begin(SOLVER_HID, nl)
             eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
@@ -270,6 +274,8 @@ class MG:
                 if self.solver_weights[i] is not None:
                     eng.set_smoother(SOLVER_HID, i, self.solver_weights[i][0],
                                      self.solver_weights[i][1])
+                if i == 0 and self.solver_weights_eo is not None:
+                    eng.set_eo_smoother(SOLVER_HID, 0, self.solver_weights_eo)
             eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
             eng.hier_end(SOLVER_HID)
             eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)

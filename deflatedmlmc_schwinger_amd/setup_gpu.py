@@ -157,6 +157,30 @@ class _EngineOperator:
         return self.eng.apply_dirac(self.hid, self.level, np.asarray(v, dtype=np.complex128))
 
 
+class _EngineSchur:
+    """Even-odd Schur complement S = D - A_eo A_oe / D of the level-0 operator of an engine
+    hierarchy, matrix-free through sw_apply_dirac (for hierarchy.smoother_weights)."""
+
+    def __init__(self, eng, hid, L, mass):
+        V = L * L
+        idx = np.arange(2 * V)
+        site = idx % V
+        even = (((site % L) + (site // L)) & 1) == 0
+        self.E, self.O = idx[even], idx[~even]
+        self.D = 4.0 + mass
+        self.eng, self.hid, self.n = eng, hid, 2 * V
+        self.shape = (self.E.size, self.E.size)
+
+    def __matmul__(self, v):
+        u = np.zeros(self.n, dtype=np.complex128)
+        u[self.E] = v
+        w = self.eng.apply_dirac(self.hid, 0, u)
+        u[:] = 0.0
+        u[self.O] = w[self.O] / self.D
+        w = self.eng.apply_dirac(self.hid, 0, u)
+        return self.D * np.asarray(v) - w[self.E]
+
+
 def device_solver_hierarchy(eng, lat, cfg, hid):
     """The solver hierarchy built ON THE GPU (solver_cfg["setup"] = "device"): test vectors by
     batched inverse iteration (first unpreconditioned on each new level, then one refinement pass
@@ -221,8 +245,15 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                 eng.set_cycle(hid, lv, cyc[0], cyc[1], cyc[2])
                 if cfg.get("smoother", "richardson") == "richardson":
                     op = _EngineOperator(eng, hid, lv, sizes[lv])
-                    eng.set_smoother(hid, lv, _hier.smoother_weights(op, cyc[0]),
-                                     _hier.smoother_weights(op, cyc[1]))
+                    proj = None
+                    if cfg.get("smoother_target", "all") == "complement":
+                        # polynomial fitted on what the coarse correction leaves: v - P R v
+                        proj = (lambda v, _lv=lv: v - eng.prolong(hid, _lv, eng.restrict(hid, _lv, v)))
+                    eng.set_smoother(hid, lv, _hier.smoother_weights(op, cyc[0], project=proj),
+                                     _hier.smoother_weights(op, cyc[1], project=proj))
+                    if lv == 0 and cfg.get("eo_smoother"):
+                        eng.set_eo_smoother(hid, 0, _hier.smoother_weights(
+                            _EngineSchur(eng, hid, L, mass), cyc[1]))
 
     eng.hier_begin(hid, nl)
     eng.set_lattice(hid, L, mass, U1, U2)

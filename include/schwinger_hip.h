@@ -70,6 +70,13 @@ int sw_set_cycle(sw_engine* h, int hid, int level, int nu_pre, int nu_post, int 
  * n_pre = n_post = 0 returns to MR(nu) of sw_set_cycle. */
 int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w_pre, int n_post,
                     const double* w_post);
+/* Even-odd (Schur-complement) post-smoother for the stencil level: n_post Richardson steps
+ * x_e <- x_e + w_k (b'_e - S x_e) on the even sites, S = D - H_eo H_oe / D, then the odd sites
+ * exactly (x_o = (b_o + H_oe x_e) / D).  Half-vector traffic per step, operator four times better
+ * conditioned; takes the place of the post-smoothing steps of sw_set_smoother on that level (no
+ * pre-smoothing).  n_post = 0 switches back.  Same role as sw_set_smoother
+ * (multigrid.py:438-439). */
+int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const double* w_post);
 /* Reference-faithful cycle at `level` ("function_iters / total_complexity in both
  * modes"): MG.one_mg_step exactly as multigrid.py:369-447 lays it out -- smooth, residual,
  * restrict, recurse, prolong, residual, smooth -- with `cycles` restart cycles of unpreconditioned
@@ -216,6 +223,7 @@ int sw_timers_reset(sw_engine* h);
 #define SW_KCLASS_MFMA_OP 12        /* k_bsr_mfma, block-structured level operator */
 #define SW_KCLASS_STENCIL_SM2 13     /* k_stencil_2step, two fused smoother steps   */
 #define SW_KCLASS_MFMA_OP2 14       /* k_bsr_mfma, level operators below level 1   */
+#define SW_KCLASS_SCHUR 15          /* k_schur_step / k_eo_hop, even-odd smoother  */
 int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);
 /* Kernel launches issued since the last reset (for launch-bound analysis). */
 int sw_launch_count(sw_engine* h, int64_t* n);

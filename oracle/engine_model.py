@@ -95,3 +95,24 @@ def cycle(As, Ps, cinv, cfg, level, B, weights=None):
     if nu_post > 0:
         X, _ = mr_smooth(A, X, B - A @ X, nu_post)
     return X
+
+
+def cycle_eo(As, Ps, cinv, cfg, B, weights, w_eo, E, O, D):
+    """The level-0 cycle with the even-odd post-smoother (sw_set_eo_smoother): coarse correction as
+    in cycle(), then w_eo Richardson steps on S = D - A_eo A_oe / D for the even sites E and the odd
+    sites O solved exactly.  B is [n, nb] in the reference order."""
+    A, P = As[0], Ps[0]
+    R = P.conj().T
+    sub = lambda v: cycle(As, Ps, cinv, cfg, 1, v, weights)   # noqa: E731
+    X = P @ sub(R @ B)
+    Aeo = A[E][:, O]
+    Aoe = A[O][:, E]
+    xe = X[E]
+    bp = B[E] - Aeo @ (B[O] / D)
+    for w in w_eo:
+        Sx = D * xe - Aeo @ (Aoe @ xe) / D
+        xe = xe + w * (bp - Sx)
+    out = np.zeros_like(B)
+    out[E] = xe
+    out[O] = (B[O] - Aoe @ xe) / D
+    return out

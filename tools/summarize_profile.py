@@ -66,6 +66,7 @@ def main(out):
             lines.append("%-72s %12.2f %12.2f %12.2f" % (k, fmb, wmb, fmb + wmb))
             tags = {"k_stencil<0,": "k_stencil<0>", "k_stencil<1,": "k_stencil<1>",
                     "k_stencil<2,": "k_stencil<2>",
+                    "k_schur_step": "k_schur_step",
                     "k_bsr_mfma<0, 4, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<0, 2, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<3, 4, true": "k_bsr_mfma(level-1 operator)",

@@ -65,6 +65,8 @@ struct EllOp {
   int bsr_KS = 0;
   int* bsr_kcol = nullptr;   // [n/16][KS] first X row of each 4-column group
   cplx* bsr_vals = nullptr;  // [n/16][KS][64] lane-packed
+  int* bsr_tmap = nullptr;   // optional: row tile -> tile of the output vector (subset operators)
+  int bsr_RT = 0;            // row tiles when != nrows / 16 (subset operators)
 };
 
 struct KrylovWS {
@@ -92,8 +94,12 @@ struct Level {
   // fixed-polynomial (Richardson) smoother: weights 1/theta_k; empty -> adaptive MR steps
   std::vector<std::complex<double>> w_pre, w_post;
   bool rich = false;
-  // even-odd post-smoother of the stencil level: Richardson weights for the Schur complement S
+  // even-odd post-smoother: Richardson weights for the Schur complement S of the even sites.
+  // Stencil level: S is the fused two-hop kernel.  Coarse (block) levels: four subset operators in
+  // MFMA block-row form, eo_op[0] = S (even x even, 9-point), [1] = F = A_eo D_oo^-1,
+  // [2] = G = D_oo^-1, [3] = Hb = D_oo^-1 A_oe
   std::vector<std::complex<double>> w_eo;
+  EllOp eo_op[4];
   std::vector<int> h_rowmap;  // natural -> internal (empty: identity)
   int* rowmap = nullptr;
   // per-level cycle workspace, [n][nbp]
@@ -371,6 +377,7 @@ static int free_op(sw_engine* h, EllOp& op) {
   SWCHK(dev_free(h, op.order));
   SWCHK(dev_free(h, op.bsr_kcol));
   SWCHK(dev_free(h, op.bsr_vals));
+  SWCHK(dev_free(h, op.bsr_tmap));
   op = EllOp();
   return 0;
 }
@@ -380,7 +387,7 @@ static int free_op(sw_engine* h, EllOp& op) {
 // ---------------------------------------------------------------------------------------------
 static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B, cplx* Y,
                       int nbp, int cat, cplx w) {
-  const int RT = op.nrows / 16;
+  const int RT = op.bsr_RT > 0 ? op.bsr_RT : op.nrows / 16;
   // MFMA column tiles per wave (8 probes each).  Small operators (a 4096-row level on 256 probes is
   // 2048 waves at NT = 4, two per SIMD once) are latency-bound: fewer tiles per wave = more waves
   int NT = h->mfma_tiles;
@@ -402,7 +409,7 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
 #define BSR_LAUNCH_S(MD, NTT, NTB, SG)                                                           \
   hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, NTB, SG>), grid, dim3(SW_BLOCK), 0, h->stream,   \
                      (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br,   \
-                     Yr, 2 * nbp, nbp, w, bmap, msub)
+                     Yr, 2 * nbp, nbp, w, bmap, msub, (const int*)op.bsr_tmap)
 #define BSR_LAUNCH(MD, NTT)                                                                     \
   do {                                                                                          \
     const bool ntio_ = h->bsr_nt && cat != T_COARSEST;                                          \
@@ -963,6 +970,22 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
     SWCHK(launch_ell(h, lv.R, 0, Bin, nullptr, lc.b, nbp, T_R));
   }
   SWCHK(coarse_correction(h, H, l, nbp));
+  if (!lv.stencil && !lv.w_eo.empty() && !xpre && lv.eo_op[0].set) {
+    // even-odd post-smoother of a block level, all four pieces on the MFMA block-row kernel:
+    //   b'_e = b_e - F b_o ;  x_e <- x_e + w_k (b'_e - S x_e) ;  x_o = G b_o - Hb x_e
+    const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+    cplx* cur = odd_steps ? lv.t : Xout;
+    cplx* nxt = odd_steps ? Xout : lv.t;
+    SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, cur, nbp, T_P));
+    SWCHK(launch_bsr(h, lv.eo_op[1], 1, Bin, Bin, lv.r, nbp, T_MVM, cplx{0.0, 0.0}));
+    for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+      SWCHK(launch_bsr(h, lv.eo_op[0], 3, cur, lv.r, nxt, nbp, T_MVM,
+                       cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()}));
+      std::swap(cur, nxt);
+    }
+    SWCHK(launch_bsr(h, lv.eo_op[2], 0, Bin, nullptr, Xout, nbp, T_MVM, cplx{0.0, 0.0}));
+    return launch_bsr(h, lv.eo_op[3], 1, Xout, Xout, Xout, nbp, T_MVM, cplx{0.0, 0.0});
+  }
   if (lv.stencil && !lv.w_eo.empty() && !xpre) {
     // even-odd post-smoother: prolongate into the buffer from which nu steps end in Xout
     const bool odd_steps = (lv.w_eo.size() & 1) != 0;
@@ -1230,6 +1253,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(free_op(h, lv.A));
     SWCHK(free_op(h, lv.P));
     SWCHK(free_op(h, lv.R));
+    for (int q = 0; q < 4; ++q) SWCHK(free_op(h, lv.eo_op[q]));
     SWCHK(dev_free(h, lv.rowmap));
     SWCHK(dev_free(h, lv.b)); SWCHK(dev_free(h, lv.x)); SWCHK(dev_free(h, lv.r));
     SWCHK(dev_free(h, lv.t));
@@ -1731,11 +1755,53 @@ int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles) {
   return 0;
 }
 
+int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int KS, const int32_t* tmap,
+                       const int32_t* kcol, const double* vals) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (which < 0 || which > 3) return sw_fail(h, "even-odd operator index %d out of [0,3]", which);
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[hid].lv[level];
+  if (lv.stencil || lv.n <= 0 || lv.n % 16) return sw_fail(h, "level %d is not a block level", level);
+  if (RT <= 0 || KS <= 0 || (KS & 3) || !tmap || !kcol || !vals) return sw_fail(h, "bad arguments");
+  const int tiles = lv.n / 16;
+  for (int i = 0; i < RT; ++i)
+    if (tmap[i] < 0 || tmap[i] >= tiles) return sw_fail(h, "tile map entry out of range");
+  for (size_t i = 0; i < (size_t)RT * KS; ++i)
+    if (kcol[i] < 0 || kcol[i] + 4 > lv.n) return sw_fail(h, "k-step column out of range");
+  EllOp& op = lv.eo_op[which];
+  SWCHK(free_op(h, op));
+  op.nrows = op.ncols = lv.n;
+  op.bsr_RT = RT;
+  op.bsr_KS = KS;
+  SWCHK(upload(h, &op.bsr_tmap, (const int*)tmap, (size_t)RT));
+  SWCHK(upload(h, &op.bsr_kcol, (const int*)kcol, (size_t)RT * KS));
+  SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, (const std::complex<double>*)vals,
+               (size_t)RT * KS * 64));
+  op.set = true;
+  return 0;
+}
+
+int sw_get_level_bsr(sw_engine* h, int hid, int level, int* KS, int32_t* kcol, double* vals) {
+  SWCHK(check_hier(h, hid, level, false));
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[hid].lv[level];
+  const EllOp& A = lv.A;
+  if (!A.set || A.bsr_KS <= 0) return sw_fail(h, "level %d has no block-row operator", level);
+  if (KS) *KS = A.bsr_KS;
+  if (!kcol || !vals) return 0;     // size query
+  SWCHK(stream_sync(h));
+  const size_t items = (size_t)(lv.n / 16) * A.bsr_KS;
+  HIPCHK(hipMemcpy(kcol, A.bsr_kcol, items * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(vals, A.bsr_vals, items * 64 * sizeof(cplx), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const double* w_post) {
   SWCHK(check_hier(h, hid, level, false));
   if (n_post < 0 || n_post > 64 || (n_post > 0 && !w_post)) return sw_fail(h, "sw_set_eo_smoother: bad arguments");
   Level& lv = h->hier[hid].lv[level];
-  if (n_post > 0 && !lv.stencil) return sw_fail(h, "the even-odd smoother is defined for the stencil level");
+  if (n_post > 0 && !lv.stencil && !(lv.eo_op[0].set && lv.eo_op[1].set && lv.eo_op[2].set && lv.eo_op[3].set))
+    return sw_fail(h, "level %d: the even-odd operators are not set (sw_set_eo_operator)", level);
   lv.w_eo.clear();
   for (int i = 0; i < n_post; ++i) lv.w_eo.emplace_back(w_post[2 * i], w_post[2 * i + 1]);
   if (n_post > 0) lv.rich = true;     // the cycle with fixed weights (vcycle_rich)

@@ -587,7 +587,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
                                                        int RT, const double* __restrict__ Xr,
                                                        const double* __restrict__ Br,
                                                        double* __restrict__ Yr, int ld, int nbp,
-                                                       cplx w, int map, int msub) {
+                                                       cplx w, int map, int msub,
+                                                       const int* __restrict__ tmap) {
   // the 4 waves of a workgroup take 4 consecutive row tiles and the SAME 64-probe chunk, so
   // the X rows they share (all of them for a dense operator, the common neighbours for a
   // block stencil) are served once from L2 and then from the CU's L1
@@ -666,9 +667,12 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
 #undef SW_BSR_MFMA
   const int c = lane & 15;
   const bool odd = (c & 1) != 0;
+  const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const size_t row = (size_t)rt * 16 + (lane >> 4) + 4 * r;
+    // tmap (optional): row tile -> tile of the OUTPUT vector it belongs to (operators that act on
+    // a subset of a level's sites, e.g. the even-odd Schur operators of a coarse level)
+    const size_t row = (size_t)ot * 16 + (lane >> 4) + 4 * r;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const double s = __shfl_xor(im[t][r], 1);

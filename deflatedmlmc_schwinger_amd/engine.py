@@ -68,6 +68,8 @@ def load_library():
     sig("sw_set_smoother", i32, vp, i32, i32, i32, vp, i32, vp)
     sig("sw_set_gmres_smoother", i32, vp, i32, i32, i32, i32)
     sig("sw_set_eo_smoother", i32, vp, i32, i32, i32, vp)
+    sig("sw_set_eo_operator", i32, vp, i32, i32, i32, i32, i32, vp, vp, vp)
+    sig("sw_get_level_bsr", i32, vp, i32, i32, P(i32), vp, vp)
     sig("sw_setup_testvectors", i32, vp, i32, i32, i32, C.c_uint64, i32, dbl, i32, i32, vp)
     sig("sw_setup_transfer", i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp)
     sig("sw_setup_galerkin", i32, vp, i32, i32, i32, vp)
@@ -125,7 +127,8 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_setup_testvectors", "sw_setup_transfer",
+    "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator",
+    "sw_get_level_bsr", "sw_setup_testvectors", "sw_setup_transfer",
     "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
@@ -243,6 +246,28 @@ class Engine:
         wq = _c128(np.asarray(w_post if w_post is not None else [], dtype=np.complex128))
         self._chk(self._lib.sw_set_eo_smoother(self._h, hid, level, wq.size,
                                                _ptr(wq) if wq.size else None), "sw_set_eo_smoother")
+
+    def set_eo_operator(self, hid, level, which, tmap, kcol, vals):
+        tmap = np.ascontiguousarray(tmap, dtype=np.int32)
+        kcol = np.ascontiguousarray(kcol, dtype=np.int32)
+        vals = _c128(vals)
+        RT, KS = kcol.shape
+        if vals.shape != (RT, KS, 64) or tmap.shape != (RT,):
+            raise EngineError("even-odd operator arrays have inconsistent shapes")
+        self._chk(self._lib.sw_set_eo_operator(self._h, hid, level, int(which), RT, KS, _ptr(tmap),
+                                               _ptr(kcol), _ptr(vals)), "sw_set_eo_operator")
+
+    def level_bsr(self, hid, level):
+        """A (device-built) level operator in MFMA block-row form: (kcol[RT, KS], vals[RT, KS, 64])."""
+        ks = C.c_int(0)
+        self._chk(self._lib.sw_get_level_bsr(self._h, hid, level, C.byref(ks), None, None),
+                  "sw_get_level_bsr")
+        RT = self.level_sizes[hid][level] // 16
+        kcol = np.empty((RT, ks.value), dtype=np.int32)
+        vals = np.empty((RT, ks.value, 64), dtype=np.complex128)
+        self._chk(self._lib.sw_get_level_bsr(self._h, hid, level, C.byref(ks), _ptr(kcol), _ptr(vals)),
+                  "sw_get_level_bsr")
+        return kcol, vals
 
     def set_gmres_smoother(self, hid, level, m, cycles):
         self._chk(self._lib.sw_set_gmres_smoother(self._h, hid, level, int(m), int(cycles)),

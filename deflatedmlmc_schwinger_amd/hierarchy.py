@@ -310,6 +310,112 @@ def schur_complement(A, L):
     return sp.csr_matrix(S), E, O, D
 
 
+def matrix_from_block_rows(kcol, vals, n):
+    """The MFMA block-row form of a level operator (kcol[RT, KS], vals[RT, KS, 64] with lane =
+    (row & 15) + 16 (col & 3)) as a SciPy CSR matrix."""
+    RT, KS = kcol.shape
+    i = np.arange(16)
+    c4 = np.arange(4)
+    rows = (np.arange(RT)[:, None, None, None] * 16 + i[None, None, None, :]
+            + np.zeros((1, KS, 4, 1), dtype=np.int64))
+    cols = kcol[:, :, None, None].astype(np.int64) + c4[None, None, :, None] + np.zeros((1, 1, 1, 16), np.int64)
+    data = np.asarray(vals).reshape(RT, KS, 4, 16)
+    keep = data != 0
+    return sp.csr_matrix((data[keep], (rows[keep], cols[keep])), shape=(n, n))
+
+
+def block_rows_from_matrix(M, row_sites, n):
+    """Pack the block rows `row_sites` (16 rows each) of an n x n sparse matrix whose non-zeros sit in
+    16 x 16 site blocks into the MFMA block-row form: (tmap[RT], kcol[RT, KS], vals[RT, KS, 64])."""
+    Mb = sp.bsr_matrix(sp.csr_matrix(M), blocksize=(16, 16))
+    Mb.sort_indices()
+    row_sites = np.asarray(row_sites, dtype=np.int64)
+    nblk = np.diff(Mb.indptr)[row_sites]
+    KB = max(1, int(nblk.max()))
+    RT = row_sites.size
+    kcol = np.zeros((RT, KB * 4), dtype=np.int32)
+    vals = np.zeros((RT, KB * 4, 64), dtype=np.complex128)
+    g = np.arange(4)
+    for r, s_ in enumerate(row_sites):
+        lo, hi = Mb.indptr[s_], Mb.indptr[s_ + 1]
+        cs = Mb.indices[lo:hi]
+        blk = Mb.data[lo:hi]                                   # [nb, 16 (i), 16 (col)]
+        kcol[r, :] = int(s_) * 16                              # padding: a valid column, zero values
+        nbk = hi - lo
+        kcol[r, :nbk * 4] = (cs[:, None] * 16 + 4 * g[None, :]).reshape(-1)
+        # vals[q*4+g, c4*16 + i] = blk[q, i, 4 g + c4]
+        b4 = blk.reshape(nbk, 16, 4, 4)                         # [q, i, g, c4]
+        vals[r, :nbk * 4, :] = b4.transpose(0, 2, 3, 1).reshape(nbk * 4, 64)
+    return row_sites.astype(np.int32), kcol, vals
+
+
+def coarse_schur_operators(A, Lc):
+    """Even-odd Schur construction for a block level (5-point stencil of 16 x 16 blocks over an
+    Lc x Lc site lattice, site-major rows).  Returns dict(S, F, G, Hb as sparse n x n matrices that are
+    non-zero on the even / odd site rows only, E_sites, O_sites, E_rows, O_rows):
+      S = D_ee - A_eo D_oo^-1 A_oe,  F = A_eo D_oo^-1,  G = D_oo^-1,  Hb = D_oo^-1 A_oe."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    ns = Lc * Lc
+    if n != ns * 16:
+        raise Exception("block level of %d rows is not %d sites x 16" % (n, ns))
+    site = np.arange(ns)
+    even_site = (((site % Lc) + (site // Lc)) & 1) == 0
+    E_sites, O_sites = site[even_site], site[~even_site]
+    row_even = np.repeat(even_site, 16)
+    ME = sp.diags(row_even.astype(float))
+    MO = sp.diags((~row_even).astype(float))
+    Ab = sp.bsr_matrix(A, blocksize=(16, 16))
+    Ab.sort_indices()
+    # diagonal blocks of the odd sites, inverted
+    dinv_blocks = np.zeros((O_sites.size, 16, 16), dtype=np.complex128)
+    for q, s_ in enumerate(O_sites):
+        lo, hi = Ab.indptr[s_], Ab.indptr[s_ + 1]
+        k = lo + int(np.searchsorted(Ab.indices[lo:hi], s_))
+        if k >= hi or Ab.indices[k] != s_:
+            raise Exception("site %d has no diagonal block" % s_)
+        dinv_blocks[q] = np.linalg.inv(Ab.data[k])
+    G = sp.bsr_matrix((dinv_blocks, O_sites, np.concatenate([[0], np.cumsum((~even_site).astype(int))])),
+                      shape=(n, n), blocksize=(16, 16)).tocsr()
+    Aeo = (ME @ A @ MO).tocsr()
+    Aoe = (MO @ A @ ME).tocsr()
+    Aee = (ME @ A @ ME).tocsr()
+    F = (Aeo @ G).tocsr()
+    Hb = (G @ Aoe).tocsr()
+    S = (Aee - Aeo @ Hb).tocsr()
+    E_rows = np.nonzero(row_even)[0]
+    O_rows = np.nonzero(~row_even)[0]
+    return {"S": S, "F": F, "G": G, "Hb": Hb, "E_sites": E_sites, "O_sites": O_sites,
+            "E_rows": E_rows, "O_rows": O_rows}
+
+
+def eo_levels_of(cfg):
+    """Levels smoothed on their even-odd Schur complement: cfg["eo_levels"], or [0] for the older
+    switch cfg["eo_smoother"] = True."""
+    lv = list(cfg.get("eo_levels", []))
+    if cfg.get("eo_smoother") and 0 not in lv:
+        lv.append(0)
+    return sorted(lv)
+
+
+def upload_coarse_eo(engines, hid, level, A_l, Lc, degree):
+    """Build the four even-odd operators of block level `level` on the host, hand them to the engines
+    and select `degree` Schur steps as its post-smoother.  Returns (weights, ops)."""
+    ops = coarse_schur_operators(A_l, Lc)
+    n = A_l.shape[0]
+    packed = [block_rows_from_matrix(ops["S"], ops["E_sites"], n),
+              block_rows_from_matrix(ops["F"], ops["E_sites"], n),
+              block_rows_from_matrix(ops["G"], ops["O_sites"], n),
+              block_rows_from_matrix(ops["Hb"], ops["O_sites"], n)]
+    E = ops["E_rows"]
+    weights = smoother_weights(sp.csr_matrix(ops["S"][E][:, E]), degree)
+    for eng in engines:
+        for which, (tmap, kcol, vals) in enumerate(packed):
+            eng.set_eo_operator(hid, level, which, tmap, kcol, vals)
+        eng.set_eo_smoother(hid, level, weights)
+    return weights, ops
+
+
 DEFAULT_SOLVER_CFG = {
     # (aggregate edge in sites of the level above, test vectors per chirality) per coarsening
     "coarsening": [(4, 8), (2, 8)],
@@ -331,7 +437,7 @@ TUNED_SOLVER_CFG_128 = {
     "coarsening": [(4, 8), (2, 8), (2, 8)],
     "cycle": [(0, 6, 0), (0, 7, 0), (0, 16, 0)],
     "smoother": "richardson",
-    "eo_smoother": True,        # level 0 smoothed on the even-odd Schur complement (6 half-vector steps)
+    "eo_levels": [0],           # levels smoothed on their even-odd Schur complement (half vectors)
     "restart": 6,
     "setup": "device",
     "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,

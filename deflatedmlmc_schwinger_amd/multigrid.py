@@ -259,9 +259,12 @@ class MG:
             else:
                 self.solver_weights.append(None)
         self.solver_weights_eo = None
-        if cfg.get("eo_smoother") and cfg.get("smoother", "richardson") == "richardson":
-            S, _, _, _ = _hier.schur_complement(sh["A"][0], L)
+        self.solver_eo = {}                   # level -> (weights, E rows, O rows) for the tests' model
+        eo_levels = _hier.eo_levels_of(cfg) if cfg.get("smoother", "richardson") == "richardson" else []
+        if 0 in eo_levels:
+            S, E0, O0, _ = _hier.schur_complement(sh["A"][0], L)
             self.solver_weights_eo = _hier.smoother_weights(S, cfg["cycle"][0][1])
+            self.solver_eo[0] = (self.solver_weights_eo, E0, O0)
         for eng in self.engines:
             eng.hier_begin(SOLVER_HID, nl)
             eng.set_lattice(SOLVER_HID, L, lat[1], lat[2], lat[3])
@@ -279,6 +282,13 @@ class MG:
             eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
             eng.hier_end(SOLVER_HID)
             eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
+        Lc = L
+        for i in range(1, nl - 1):
+            Lc //= cfg["coarsening"][i - 1][0]
+            if i in eo_levels:
+                w, ops = _hier.upload_coarse_eo(self.engines, SOLVER_HID, i, sh["A"][i], Lc,
+                                                cfg["cycle"][i][1])
+                self.solver_eo[i] = (w, ops["E_rows"], ops["O_rows"])
         self._have_solver_hier = True
         self.solver_testvectors = sh["tv"]
         self.solver_info = {"levels": [a.shape[0] for a in sh["A"]],

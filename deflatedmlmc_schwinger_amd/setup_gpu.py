@@ -199,6 +199,7 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
     maxiter = int(cfg.get("setup_maxiter", 32))
     refine = int(cfg.get("setup_refine", 1))
     seed = int(cfg.get("setup_seed", 7))
+    eo_levels = _hier.eo_levels_of(cfg)
     t0 = time.time()
     log = []
     geo = []
@@ -251,9 +252,15 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                         proj = (lambda v, _lv=lv: v - eng.prolong(hid, _lv, eng.restrict(hid, _lv, v)))
                     eng.set_smoother(hid, lv, _hier.smoother_weights(op, cyc[0], project=proj),
                                      _hier.smoother_weights(op, cyc[1], project=proj))
-                    if lv == 0 and cfg.get("eo_smoother"):
+                    if lv == 0 and 0 in eo_levels:
                         eng.set_eo_smoother(hid, 0, _hier.smoother_weights(
                             _EngineSchur(eng, hid, L, mass), cyc[1]))
+                    elif lv in eo_levels:
+                        # block level: its operator comes back in block-row form, the four even-odd
+                        # operators are formed on the host (batched 16 x 16 algebra) and uploaded
+                        kcol, vals = eng.level_bsr(hid, lv)
+                        A_l = _hier.matrix_from_block_rows(kcol, vals, sizes[lv])
+                        _hier.upload_coarse_eo([eng], hid, lv, A_l, geo[lv - 1]["Lc"], cyc[1])
 
     eng.hier_begin(hid, nl)
     eng.set_lattice(hid, L, mass, U1, U2)

@@ -77,6 +77,17 @@ int sw_set_smoother(sw_engine* h, int hid, int level, int n_pre, const double* w
  * pre-smoothing).  n_post = 0 switches back.  Same role as sw_set_smoother
  * (multigrid.py:438-439). */
 int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const double* w_post);
+/* The same construction on a coarse (block) level, whose operator is a 5-point stencil of 16x16
+ * blocks over the coarse sites: four operators that act on the even or odd sites only, in MFMA
+ * block-row form -- which = 0: S = D_ee - A_eo D_oo^-1 A_oe (9-point), 1: F = A_eo D_oo^-1,
+ * 2: G = D_oo^-1, 3: Hb = D_oo^-1 A_oe.  RT row tiles, KS k-steps per tile (multiple of 4),
+ * tmap[RT] = tile (site) of the level vector each row tile writes, kcol[RT*KS] = first level row of
+ * each 4-column group, vals[RT*KS*64] complex128 lane-packed as for the level operators.  With all
+ * four set, sw_set_eo_smoother accepts the level.  sw_get_level_bsr reads a (device-built) level
+ * operator back in that form (kcol = vals = NULL: only *KS). */
+int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int KS, const int32_t* tmap,
+                       const int32_t* kcol, const double* vals);
+int sw_get_level_bsr(sw_engine* h, int hid, int level, int* KS, int32_t* kcol, double* vals);
 /* Reference-faithful cycle at `level` ("function_iters / total_complexity in both
  * modes"): MG.one_mg_step exactly as multigrid.py:369-447 lays it out -- smooth, residual,
  * restrict, recurse, prolong, residual, smooth -- with `cycles` restart cycles of unpreconditioned

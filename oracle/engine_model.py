@@ -60,9 +60,31 @@ def richardson(A, B, X, weights, from_zero):
     return X
 
 
-def cycle(As, Ps, cinv, cfg, level, B, weights=None):
+def eo_post_smooth(A, B, X, w_eo, E, O):
+    """Even-odd post-smoothing of one level (sw_set_eo_smoother): x_e <- x_e + w (b'_e - S x_e) on the
+    rows E with S = A_ee - A_eo A_oo^-1 A_oe, b'_e = b_e - A_eo A_oo^-1 b_o, then the rows O exactly.
+    A_oo is (block) diagonal; the model inverts it densely per solve (small test operands)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    A = sp.csr_matrix(A)
+    Aee, Aeo = A[E][:, E], A[E][:, O]
+    Aoe, Aoo = A[O][:, E], sp.csc_matrix(A[O][:, O])
+    lu = spla.splu(Aoo)
+    xe = X[E]
+    bp = B[E] - Aeo @ lu.solve(B[O])
+    for w in w_eo:
+        Sx = Aee @ xe - Aeo @ lu.solve(Aoe @ xe)
+        xe = xe + w * (bp - Sx)
+    out = np.zeros_like(B)
+    out[E] = xe
+    out[O] = lu.solve(B[O] - Aoe @ xe)
+    return out
+
+
+def cycle(As, Ps, cinv, cfg, level, B, weights=None, eo=None):
     """cfg[l] = (nu_pre, nu_post, kcycle); B is [n, nb].  weights[l] = (w_pre, w_post) selects the
-    fixed-polynomial smoother at level l (None: adaptive MR steps)."""
+    fixed-polynomial smoother at level l (None: adaptive MR steps); eo[l] = (w_eo, E, O) replaces the
+    post-smoother of level l by the even-odd Schur smoother."""
     last = len(As) - 1
     if level == last:
         return np.asarray(cinv) @ B
@@ -71,15 +93,18 @@ def cycle(As, Ps, cinv, cfg, level, B, weights=None):
     R = P.conj().T
     if weights is not None and weights[level] is not None:
         w_pre, w_post = weights[level]
-        if len(w_pre):
+        use_eo = eo is not None and level in eo
+        if len(w_pre) and not use_eo:
             X = richardson(A, B, None, w_pre, True)
             Bc = R @ (B - A @ X)
         else:
             X = None
             Bc = R @ B
-        sub = lambda v: cycle(As, Ps, cinv, cfg, level + 1, v, weights)   # noqa: E731
+        sub = lambda v: cycle(As, Ps, cinv, cfg, level + 1, v, weights, eo)   # noqa: E731
         Xc = fgmres_fixed(As[level + 1], Bc, sub, kc) if (kc > 0 and level + 1 < last) else sub(Bc)
         X = P @ Xc if X is None else X + P @ Xc
+        if use_eo:
+            return eo_post_smooth(A, B, X, *eo[level])
         return richardson(A, B, X, w_post, False)
     if nu_pre > 0:
         X, res = mr_smooth(A, np.zeros_like(B), B.copy(), nu_pre)

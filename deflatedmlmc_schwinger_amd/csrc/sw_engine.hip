@@ -210,6 +210,7 @@ struct sw_engine {
   std::vector<hipEvent_t> evpool;
   double tacc[T_NCAT] = {0};
   int64_t tcount[T_NCAT] = {0};
+  double twork[T_NCAT] = {0};   // arithmetic issued per class while profiling (flops, MFMA classes)
   int64_t launches = 0;
   int* d_notconv = nullptr;
   int* h_notconv = nullptr;  // pinned
@@ -400,9 +401,12 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   dim3 grid = (bmap == 0) ? dim3(RBn, NCn) : dim3(RBn * NCn);
   // level-1 operator of the solver hierarchy vs. the smaller operators below it (separate stats)
   const int n1 = h->hier[h->solver_hid].nlevels > 1 ? h->hier[h->solver_hid].lv[1].n : 0;
-  LaunchScope ls(h, cat == T_COARSEST ? T_MFMA_DENSE
-                                      : (cat == T_MVM ? (op.nrows == n1 || n1 == 0 ? T_MFMA_OP : T_MFMA_OP2)
-                                                      : cat));
+  const int cls = cat == T_COARSEST ? T_MFMA_DENSE
+                                    : (cat == T_MVM ? (op.nrows == n1 || n1 == 0 ? T_MFMA_OP : T_MFMA_OP2)
+                                                    : cat);
+  LaunchScope ls(h, cls);
+  // 16 rows x 4 columns x nbp probes x 8 flops per complex multiply-add, per (tile, k-step)
+  if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
@@ -922,6 +926,9 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
   a.nbp = nbp;
   a.nt_store = 0;
   a.tile_w = lv.L;
+  // five lattice rows (2 KiB per site and 64-probe chunk, half the sites) must fit an XCD's L2
+  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
   a.w = cplx{0.0, 0.0};
   const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
   const dim3 grid(bpc * (nbp / 64));
@@ -2659,6 +2666,7 @@ int sw_timers_reset(sw_engine* h) {
   for (int i = 0; i < T_NCAT; ++i) {
     h->tacc[i] = 0.0;
     h->tcount[i] = 0;
+    h->twork[i] = 0.0;
   }
   h->launches = 0;
   return 0;
@@ -2669,6 +2677,12 @@ int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches
   SWCHK(stream_sync(h));
   *total_ms = h->tacc[which];
   *launches = h->tcount[which];
+  return 0;
+}
+int sw_kernel_work(sw_engine* h, int which, double* work) {
+  if (!h || !work) return 1;
+  if (which < 0 || which >= T_NCAT) return sw_fail(h, "kernel class %d out of range", which);
+  *work = h->twork[which];
   return 0;
 }
 int sw_launch_count(sw_engine* h, int64_t* n) {

@@ -400,11 +400,15 @@ __device__ __forceinline__ void hop_acc(Site2& acc, cplx u, Site2 psi) {
 __device__ __forceinline__ int wrap_p(int v, int L) { return (v + 1 == L) ? 0 : v + 1; }
 __device__ __forceinline__ int wrap_m(int v, int L) { return (v == 0) ? L - 1 : v - 1; }
 
-// site (x, y) of parity q from its index sh in [0, V/2)
-__device__ __forceinline__ void eo_site(int sh, int q, int L, int& x, int& y) {
-  const int hl = L >> 1;
-  y = sh / hl;
-  x = 2 * (sh - y * hl) + ((q + y) & 1);
+// site (x, y) of parity q for work item `it` in [0, V/2): the items walk x-tiles of tw lattice
+// columns (tw/2 sites of one parity per row), row by row inside a tile, so that the five lattice
+// rows a Schur step touches stay in the XCD's L2 on large lattices (as k_stencil's tile walk)
+__device__ __forceinline__ void eo_site(int it, int q, int L, int tw, int& x, int& y) {
+  const int ht = tw >> 1;
+  const int tile = it / (ht * L);
+  const int rem = it - tile * (ht * L);
+  y = rem / ht;
+  x = 2 * (tile * ht + (rem - y * ht)) + ((q + y) & 1);
 }
 
 // out(n) = alpha * Uv(n) + beta * (H src)(n)  on the sites n of parity Q; src on the other parity.
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const cplx* __restrict__ Uv
   const int sh = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (sh >= Vh) return;
   int x, y;
-  eo_site(sh, Q, L, x, y);
+  eo_site(sh, Q, L, a.tile_w, x, y);
   const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
   const cplx* S = src + col;
   Site2 acc;
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const cplx* __restrict_
   const int sh = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (sh >= Vh) return;
   int x, y;
-  eo_site(sh, 0, L, x, y);
+  eo_site(sh, 0, L, a.tile_w, x, y);
   const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
   const int xpp = wrap_p(xp, L), xmm = wrap_m(xm, L), ypp = wrap_p(yp, L), ymm = wrap_m(ym, L);
   const cplx* Xc = X + col;

@@ -93,6 +93,7 @@ def load_library():
     sig("sw_probes_upload_slot", i32, vp, i32, i32, i32, vp)
     sig("sw_probes_select", i32, vp, i32)
     sig("sw_kernel_stats", i32, vp, i32, P(dbl), P(i64))
+    sig("sw_kernel_work", i32, vp, i32, P(dbl))
     sig("sw_comm_unique_id", i32, vp)
     sig("sw_comm_init", i32, vp, i32, i32, vp)
     sig("sw_allreduce_stats", i32, vp, vp)
@@ -132,7 +133,7 @@ EXPORTED_SYMBOLS = (
     "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
-    "sw_kernel_stats", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
+    "sw_kernel_stats", "sw_kernel_work", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
     "sw_comm_unique_id", "sw_comm_init", "sw_allreduce_stats", "sw_comm_destroy",
     "sw_bench_dirac", "sw_set_profiling", "sw_timers", "sw_timers_reset", "sw_launch_count",
     "sw_mt_create", "sw_mt_destroy", "sw_mt_skip", "sw_mt_raw", "sw_mt_rademacher",
@@ -471,6 +472,11 @@ class Engine:
         self._chk(self._lib.sw_kernel_stats(self._h, which, C.byref(ms), C.byref(cnt)),
                   "sw_kernel_stats")
         return ms.value, int(cnt.value)
+
+    def kernel_work(self, which):
+        w = C.c_double(0.0)
+        self._chk(self._lib.sw_kernel_work(self._h, which, C.byref(w)), "sw_kernel_work")
+        return w.value
 
     def hutch_run(self, mode, level, tol, maxiter=1000):
         self._chk(self._lib.sw_hutch_run(self._h, mode, level, float(tol), int(maxiter)),

@@ -236,6 +236,9 @@ int sw_timers_reset(sw_engine* h);
 #define SW_KCLASS_MFMA_OP2 14       /* k_bsr_mfma, level operators below level 1   */
 #define SW_KCLASS_SCHUR 15          /* k_schur_step / k_eo_hop, even-odd smoother  */
 int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);
+/* Floating-point operations issued by the launches of an MFMA kernel class since the last reset
+ * (profiling on): 8 flops per complex multiply-add over every (row tile, k-step, probe). */
+int sw_kernel_work(sw_engine* h, int which, double* work);
 /* Kernel launches issued since the last reset (for launch-bound analysis). */
 int sw_launch_count(sw_engine* h, int64_t* n);
 

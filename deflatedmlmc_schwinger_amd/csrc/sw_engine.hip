@@ -137,6 +137,7 @@ struct sw_engine {
   int restart = 24;
   int solver_hid = 0;
   bool use_mfma = true;
+  bool bsr_splitk = false;  // split-K kernel for small operators: measured SLOWER (28 vs 19 us on the 4096-row level), kept as a switch
   int bsr_stages = 4, dense_stages = 8;   // software-pipeline depth of k_bsr_mfma (k-steps in flight)
   int bsr_map = 1, bsr_sub = 8, dense_map = 0;   // block orderings of k_bsr_mfma (see the kernel)
   bool bsr_nt = true;     // non-temporal B loads / Y stores in k_bsr_mfma on level operators
@@ -407,6 +408,23 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   LaunchScope ls(h, cls);
   // 16 rows x 4 columns x nbp probes x 8 flops per complex multiply-add, per (tile, k-step)
   if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
+  if (h->bsr_splitk && NT == 2 && (long long)RT * ((2 * nbp) / 32) < 4096 && op.bsr_KS >= 8) {
+    // small operator: four waves per (tile, chunk), each a quarter of the k-steps
+    const int NC2 = (2 * nbp) / 32;
+    const bool ntio = h->bsr_nt && cat != T_COARSEST;
+    const dim3 gsk(RT * NC2);
+#define SK_LAUNCH(MD, NTB)                                                                       \
+  hipLaunchKernelGGL((swk::k_bsr_mfma_sk<MD, 2, NTB>), gsk, dim3(SW_BLOCK), 0, h->stream,         \
+                     (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT,            \
+                     (const double*)X, (const double*)B, (double*)Y, 2 * nbp, w,                  \
+                     (const int*)op.bsr_tmap)
+    if (mode == 0) { if (ntio) SK_LAUNCH(0, true); else SK_LAUNCH(0, false); }
+    else if (mode == 1) { if (ntio) SK_LAUNCH(1, true); else SK_LAUNCH(1, false); }
+    else { if (ntio) SK_LAUNCH(3, true); else SK_LAUNCH(3, false); }
+#undef SK_LAUNCH
+    KLAUNCH_CHECK();
+    return 0;
+  }
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
@@ -1864,6 +1882,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (std::strcmp(name, "bsr_stages") == 0 || std::strcmp(name, "dense_stages") == 0) {
     if (value != 2.0 && value != 4.0 && value != 8.0) return sw_fail(h, "%s must be 2, 4 or 8", name);
     (name[0] == 'd' ? h->dense_stages : h->bsr_stages) = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "bsr_splitk") == 0) {
+    h->bsr_splitk = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "bsr_nt") == 0) {

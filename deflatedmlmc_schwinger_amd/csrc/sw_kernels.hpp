@@ -585,6 +585,41 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 // ------------------------------------------------------------------------------------------
 typedef double sw_double4 __attribute__((ext_vector_type(4)));
 
+// epilogue of the block-row kernels: re/im exchange between neighbour lanes, mode arithmetic, store
+template <int MODE, int NT, bool NTIO>
+__device__ __forceinline__ void bsr_store(const sw_double4 (&re)[NT], const sw_double4 (&im)[NT], int rt,
+                                          int c0, int lane, const int* __restrict__ tmap,
+                                          const double* __restrict__ Xr,
+                                          const double* __restrict__ Br, double* __restrict__ Yr,
+                                          int ld, cplx w) {
+  const int c = lane & 15;
+  const bool odd = (c & 1) != 0;
+  const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // tmap (optional): row tile -> tile of the OUTPUT vector it belongs to (operators that act on
+    // a subset of a level's sites, e.g. the even-odd Schur operators of a coarse level)
+    const size_t row = (size_t)ot * 16 + (lane >> 4) + 4 * r;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double s = __shfl_xor(im[t][r], 1);
+      double y = odd ? re[t][r] + s : re[t][r] - s;
+      const size_t off = row * ld + c0 + t * 16 + c;
+      // B is read once, by exactly this lane: streamed past L2 (nt) when NTIO, so that the operator's
+      // values, which every probe chunk of this XCD's row band re-reads, stay resident there
+      // (hoisting these loads above the MFMA loop was measured 5 % SLOWER: register pressure)
+      if (MODE == 1) y = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
+      if (MODE == 3) {
+        const double tt = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
+        const double tp = __shfl_xor(tt, 1);
+        y = Xr[off] + w.x * tt + (odd ? w.y * tp : -w.y * tp);
+      }
+      if (NTIO) __builtin_nontemporal_store(y, &Yr[off]);
+      else Yr[off] = y;
+    }
+  }
+}
+
 template <int MODE, int NT, bool NTIO = false, int STG = 2>
 __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ Ap,
                                                        const int* __restrict__ kcol, int KS,
@@ -669,32 +704,89 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   }
 #undef SW_BSR_LOAD
 #undef SW_BSR_MFMA
-  const int c = lane & 15;
-  const bool odd = (c & 1) != 0;
-  const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
+  bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-K variant for operators too small to fill the chip with one wave per (tile, chunk): a
+// 4096-row level on 256 probes is 2048-4096 waves of 20-36 SEQUENTIAL k-steps each, a 1024^2 dense
+// inverse 1024 waves of 256 -- launch-to-finish time is the length of that chain.  Here the four
+// waves of a workgroup share ONE (row tile, probe chunk): wave q takes k-steps q, q+4, q+8, ...
+// (so the four A reads of a round are one contiguous 4-KiB block), the partial accumulators meet
+// in LDS, wave 0 runs the epilogue.  Four times the waves, a quarter of the chain.
+// ------------------------------------------------------------------------------------------
+template <int MODE, int NT, bool NTIO>
+__global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma_sk(const cplx* __restrict__ Ap,
+                                                          const int* __restrict__ kcol, int KS,
+                                                          int RT, const double* __restrict__ Xr,
+                                                          const double* __restrict__ Br,
+                                                          double* __restrict__ Yr, int ld, cplx w,
+                                                          const int* __restrict__ tmap) {
+  __shared__ double red[3][NT * 8][64];
+  const int lane = threadIdx.x & 63;
+  const int q = threadIdx.x >> 6;
+  const int rt = blockIdx.x % RT;
+  const int cy = blockIdx.x / RT;
+  const int c0 = cy * (16 * NT);
+  const cplx* a = Ap + (size_t)rt * KS * 64 + lane;
+  const int* kc = kcol + (size_t)rt * KS;
+  const double* b = Xr + (size_t)(lane >> 4) * ld + c0 + (lane & 15);
+  sw_double4 re[NT], im[NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // tmap (optional): row tile -> tile of the OUTPUT vector it belongs to (operators that act on
-    // a subset of a level's sites, e.g. the even-odd Schur operators of a coarse level)
-    const size_t row = (size_t)ot * 16 + (lane >> 4) + 4 * r;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const double s = __shfl_xor(im[t][r], 1);
-      double y = odd ? re[t][r] + s : re[t][r] - s;
-      const size_t off = row * ld + c0 + t * 16 + c;
-      // B is read once, by exactly this lane: streamed past L2 (nt) when NTIO, so that the operator's
-      // values, which every probe chunk of this XCD's row band re-reads, stay resident there
-      // (hoisting these loads above the MFMA loop was measured 5 % SLOWER: register pressure)
-      if (MODE == 1) y = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
-      if (MODE == 3) {
-        const double tt = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
-        const double tp = __shfl_xor(tt, 1);
-        y = Xr[off] + w.x * tt + (odd ? w.y * tp : -w.y * tp);
-      }
-      if (NTIO) __builtin_nontemporal_store(y, &Yr[off]);
-      else Yr[off] = y;
+  for (int t = 0; t < NT; ++t) {
+    re[t] = sw_double4{0.0, 0.0, 0.0, 0.0};
+    im[t] = re[t];
+  }
+  // two register stages over this wave's k-steps q, q+4, ...
+  cplx m0, m1;
+  double x0[NT], x1[NT];
+#define SW_SK_LOAD(M_, X_, KSI)                                 \
+  {                                                             \
+    const int ks_ = ((KSI) < KS) ? (KSI) : q;                   \
+    M_ = a[(size_t)ks_ * 64];                                   \
+    const double* bk_ = b + (size_t)kc[ks_] * ld;               \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) X_[t] = bk_[t * 16]; \
+  }
+#define SW_SK_MFMA(M_, X_)                                                         \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                 \
+    re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.x, X_[t], re[t], 0, 0, 0);     \
+    im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.y, X_[t], im[t], 0, 0, 0);     \
+  }
+  SW_SK_LOAD(m0, x0, q);
+  SW_SK_LOAD(m1, x1, q + 4);
+  for (int ks = q; ks < KS; ks += 8) {
+    __builtin_amdgcn_sched_barrier(0);
+    SW_SK_MFMA(m0, x0);
+    __builtin_amdgcn_sched_barrier(0);
+    SW_SK_LOAD(m0, x0, ks + 8);
+    if (ks + 4 < KS) {
+      __builtin_amdgcn_sched_barrier(0);
+      SW_SK_MFMA(m1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+      SW_SK_LOAD(m1, x1, ks + 12);
     }
   }
+#undef SW_SK_LOAD
+#undef SW_SK_MFMA
+  if (q > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[q - 1][t * 8 + r][lane] = re[t][r];
+        red[q - 1][t * 8 + 4 + r][lane] = im[t][r];
+      }
+  }
+  __syncthreads();
+  if (q != 0) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      re[t][r] += red[0][t * 8 + r][lane] + red[1][t * 8 + r][lane] + red[2][t * 8 + r][lane];
+      im[t][r] += red[0][t * 8 + 4 + r][lane] + red[1][t * 8 + 4 + r][lane] + red[2][t * 8 + 4 + r][lane];
+    }
+  bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
 }
 
 // ------------------------------------------------------------------------------------------

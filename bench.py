@@ -154,7 +154,7 @@ def run(args):
         cyc = [[0, 7, 3]] * (len(depth) - 1) + [[0, 7, 0]]
         # GPU-side setup: inverse iteration, per-aggregate QR, P/R and R A P on the device
         cyc[0] = [0, 6, 3]          # level 0 smoothed on its even-odd Schur complement (6 half-vector steps)
-        scfg = {"coarsening": depth, "cycle": cyc, "restart": 8, "eo_levels": [0],
+        scfg = {"coarsening": depth, "cycle": cyc, "restart": 3, "eo_levels": [0],
                 "setup": os.environ.get("SW_SYNTH_SETUP", "device"),
                 "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1}
         if args.cfg:

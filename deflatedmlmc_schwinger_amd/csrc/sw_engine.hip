@@ -162,6 +162,9 @@ struct sw_engine {
   // against its TRUE residual and continued when the recurrence was optimistic
   bool cgs2 = false;
   bool verify = true;
+  // second Gram-Schmidt pass in the short inner Krylov cycles (K-cycle, GMRES smoother): they are
+  // preconditioners of 2-30 steps whose result feeds a flexible outer iteration, one pass suffices
+  bool inner_cgs2 = false;
   // deflation
   int kd = 0;
   cplx* U = nullptr;  // [n0][kd] internal row order
@@ -1080,7 +1083,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
       // pass 1: raw dots d1 = Vt^H w, coefficients c = svec^2 d1 ; w -= Vt c
       SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1));
-      if (h->cgs2 || !outer) {
+      if (h->cgs2 || (!outer && h->inner_cgs2)) {
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, nullptr));
         // pass 2 (re-orthogonalisation): d2 = Vt^H w ; w -= Vt (svec^2 d2) ; ||w||^2
         SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2, ws.sc.svec, ws.c1));
@@ -1922,6 +1925,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "cgs2") == 0) {
     h->cgs2 = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "inner_cgs2") == 0) {
+    h->inner_cgs2 = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "verify") == 0) {

@@ -438,7 +438,7 @@ TUNED_SOLVER_CFG_128 = {
     "cycle": [(0, 6, 0), (0, 5, 0), (0, 14, 0)],
     "smoother": "richardson",
     "eo_levels": [0, 1, 2],     # levels smoothed on their even-odd Schur complement (half vectors)
-    "restart": 6,
+    "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count
     "setup": "device",
     "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,
 }

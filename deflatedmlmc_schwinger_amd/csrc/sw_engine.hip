@@ -19,6 +19,7 @@
 #include <vector>
 
 using swk::cplx;
+using swk::cplxf;
 using swk::PtrList;
 
 #define SW_MAXM 32  // engine restart cap (<= SW_MAX_KRYLOV)
@@ -67,6 +68,10 @@ struct EllOp {
   cplx* bsr_vals = nullptr;  // [n/16][KS][64] lane-packed
   int* bsr_tmap = nullptr;   // optional: row tile -> tile of the output vector (subset operators)
   int bsr_RT = 0;            // row tiles when != nrows / 16 (subset operators)
+  // complex64 mirrors of the value arrays (same index arrays), made on demand for the
+  // single-precision preconditioner (option precond_f32)
+  cplxf* vals32 = nullptr;
+  cplxf* bsr_vals32 = nullptr;
 };
 
 struct KrylovWS {
@@ -105,6 +110,11 @@ struct Level {
   // per-level cycle workspace, [n][nbp]
   int ws_nbp = 0;
   cplx *b = nullptr, *x = nullptr, *r = nullptr, *t = nullptr;
+  // single-precision preconditioner: link mirrors, cycle workspace and the boundary pair
+  // (i32: cast of the fp64 input, o32: result before the cast back)
+  cplxf *U1f = nullptr, *U2f = nullptr;
+  int ws32_nbp = 0;
+  cplxf *b32 = nullptr, *x32 = nullptr, *r32 = nullptr, *t32 = nullptr, *i32 = nullptr, *o32 = nullptr;
   // reference-faithful smoother: gm_cycles restart cycles of unpreconditioned GMRES(gm_m) from a
   // zero guess, the engine's counterpart of lgmres(maxiter=smooth_iters) with inner_m = 30
   // (multigrid.py:393-394,438-439).  gm_m == 0: off
@@ -122,6 +132,7 @@ struct Hier {
   Level lv[SW_MAX_LEVELS];
   EllOp cinv;
   bool ready = false;
+  bool f32_valid = false;   // the complex64 mirrors match the operators (cleared by every setter)
 };
 
 struct EventRec {
@@ -146,6 +157,8 @@ struct sw_engine {
   int bench_mode = 0;      // operator mode sw_bench_dirac times (0: Y=AX, 1: residual, 2: smoother step)
   bool mfma_ops = true;   // MFMA block-row kernel also for block-structured level operators
   int mfma_tiles = 4;
+  int f32_tiles = 0;          // tiles of 16 probes per wave in k_bsr_mfma_f32 (0: automatic)
+  int f32_stages = 4, f32_dense_stages = 8;
   int mfma_small_tiles = 2;   // tiles per wave for operators too small to fill the chip (0: off)
   // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
@@ -165,6 +178,10 @@ struct sw_engine {
   // second Gram-Schmidt pass in the short inner Krylov cycles (K-cycle, GMRES smoother): they are
   // preconditioners of 2-30 steps whose result feeds a flexible outer iteration, one pass suffices
   bool inner_cgs2 = false;
+  // single-precision preconditioner: every application of a multigrid cycle as the preconditioner of
+  // an fp64 flexible GMRES (and sw_vcycle) runs in complex64 on the f32 matrix cores -- operands cast
+  // at the boundary, residuals / orthogonalisation / verification stay fp64
+  bool precond_f32 = false;
   // deflation
   int kd = 0;
   cplx* U = nullptr;  // [n0][kd] internal row order
@@ -383,6 +400,8 @@ static int free_op(sw_engine* h, EllOp& op) {
   SWCHK(dev_free(h, op.bsr_kcol));
   SWCHK(dev_free(h, op.bsr_vals));
   SWCHK(dev_free(h, op.bsr_tmap));
+  SWCHK(dev_free(h, op.vals32));
+  SWCHK(dev_free(h, op.bsr_vals32));
   op = EllOp();
   return 0;
 }
@@ -1037,6 +1056,289 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-precision preconditioner (option precond_f32).  The cycle below is vcycle_rich's even-odd /
+// fixed-polynomial cycle on complex64 mirrors of the operators: half the bytes on every HBM-bound
+// kernel and the f32 matrix cores (twice the fp64 rate on gfx950) for the block operators.  It is only
+// ever used INSIDE an fp64 flexible GMRES, whose residuals, orthogonalisation and true-residual
+// verification are untouched, so the solve converges to the same fp64 tolerance.
+// Supported: fixed-polynomial (Richardson) levels without pre-smoothing and without K-cycles, the
+// stencil level smoothed even-odd -- i.e. the tuned configurations; anything else fails loudly.
+// ---------------------------------------------------------------------------------------------
+template <class CI, class CO>
+static int cast_vec(sw_engine* h, const CI* src, CO* dst, size_t count, int cat = T_OTHER) {
+  LaunchScope ls(h, cat);
+  hipLaunchKernelGGL((swk::k_cast<CI, CO>), dim3((unsigned)((count + SW_BLOCK - 1) / SW_BLOCK)),
+                     dim3(SW_BLOCK), 0, h->stream, src, dst, count);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+static int mirror_op32(sw_engine* h, EllOp& op) {
+  if (!op.set) return 0;
+  if (op.vals && !op.vals32) {
+    const size_t cnt = (size_t)op.ngroups * op.K * op.G;
+    SWCHK(dev_realloc(h, &op.vals32, cnt));
+    SWCHK(cast_vec(h, (const cplx*)op.vals, op.vals32, cnt));
+  }
+  if (op.bsr_vals && op.bsr_KS > 0 && !op.bsr_vals32) {
+    const int RT = op.bsr_RT > 0 ? op.bsr_RT : op.nrows / 16;
+    const size_t cnt = (size_t)RT * op.bsr_KS * 64;
+    SWCHK(dev_realloc(h, &op.bsr_vals32, cnt));
+    SWCHK(cast_vec(h, (const cplx*)op.bsr_vals, op.bsr_vals32, cnt));
+  }
+  return 0;
+}
+
+static int drop_op32(sw_engine* h, EllOp& op) {
+  SWCHK(dev_free(h, op.vals32));
+  op.vals32 = nullptr;
+  SWCHK(dev_free(h, op.bsr_vals32));
+  op.bsr_vals32 = nullptr;
+  return 0;
+}
+
+// (re)build every complex64 mirror of a hierarchy after its operators changed
+static int ensure_f32(sw_engine* h, Hier& H) {
+  if (H.f32_valid) return 0;
+  for (int l = 0; l < H.nlevels; ++l) {
+    Level& lv = H.lv[l];
+    EllOp* ops[7] = {&lv.A, &lv.P, &lv.R, &lv.eo_op[0], &lv.eo_op[1], &lv.eo_op[2], &lv.eo_op[3]};
+    for (EllOp* op : ops) {
+      SWCHK(drop_op32(h, *op));
+      SWCHK(mirror_op32(h, *op));
+    }
+    if (lv.stencil && lv.U1) {
+      const size_t V = (size_t)lv.L * lv.L;
+      SWCHK(dev_realloc(h, &lv.U1f, V));
+      SWCHK(dev_realloc(h, &lv.U2f, V));
+      SWCHK(cast_vec(h, (const cplx*)lv.U1, lv.U1f, V));
+      SWCHK(cast_vec(h, (const cplx*)lv.U2, lv.U2f, V));
+    }
+  }
+  SWCHK(drop_op32(h, H.cinv));
+  SWCHK(mirror_op32(h, H.cinv));
+  H.f32_valid = true;
+  return 0;
+}
+
+static int ensure_level_ws32(sw_engine* h, Level& lv, int nbp) {
+  if (lv.ws32_nbp == nbp && lv.b32) return 0;
+  const size_t cnt = (size_t)lv.n * nbp;
+  SWCHK(dev_realloc(h, &lv.b32, cnt));
+  SWCHK(dev_realloc(h, &lv.x32, cnt));
+  SWCHK(dev_realloc(h, &lv.r32, cnt));
+  SWCHK(dev_realloc(h, &lv.t32, cnt));
+  SWCHK(dev_realloc(h, &lv.i32, cnt));
+  SWCHK(dev_realloc(h, &lv.o32, cnt));
+  lv.ws32_nbp = nbp;
+  return 0;
+}
+
+static int launch_bsr32(sw_engine* h, const EllOp& op, int mode, const cplxf* X, const cplxf* B, cplxf* Y,
+                        int nbp, int cat, cplxf w) {
+  if (!op.bsr_vals32) return sw_fail(h, "internal: complex64 mirror of a block-row operator missing");
+  const int RT = op.bsr_RT > 0 ? op.bsr_RT : op.nrows / 16;
+  // tiles of 16 probes per wave: 4 (64 probes) unless the operator is too small to fill the chip
+  int NT = 4;
+  if ((long long)RT * (nbp / 64) < 4096) NT = 2;
+  if (h->f32_tiles == 1 || h->f32_tiles == 2 || h->f32_tiles == 4) NT = h->f32_tiles;
+  const int RBn = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, NCn = nbp / (16 * NT);
+  const int bmap = (cat == T_COARSEST) ? 0 : 1;
+  const int n1 = h->hier[h->solver_hid].nlevels > 1 ? h->hier[h->solver_hid].lv[1].n : 0;
+  const int cls = cat == T_COARSEST ? T_MFMA_DENSE
+                                    : (cat == T_MVM ? (op.nrows == n1 || n1 == 0 ? T_MFMA_OP : T_MFMA_OP2)
+                                                    : cat);
+  LaunchScope ls(h, cls);
+  if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
+  const dim3 grid(RBn * NCn);
+  const int stg = (cat == T_COARSEST) ? h->f32_dense_stages : h->f32_stages;
+#define BSRF_LAUNCH(MD, NTT, SG)                                                                  \
+  hipLaunchKernelGGL((swk::k_bsr_mfma_f32<MD, NTT, SG>), grid, dim3(SW_BLOCK), 0, h->stream,      \
+                     (const cplxf*)op.bsr_vals32, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, B, Y, \
+                     nbp, w, bmap, (const int*)op.bsr_tmap)
+#define BSRF_STG(MD, NTT)                      \
+  do {                                         \
+    if (stg >= 8) BSRF_LAUNCH(MD, NTT, 8);     \
+    else if (stg >= 4) BSRF_LAUNCH(MD, NTT, 4); \
+    else BSRF_LAUNCH(MD, NTT, 2);              \
+  } while (0)
+#define BSRF_MODE(NTT)                         \
+  do {                                         \
+    if (mode == 0) BSRF_STG(0, NTT);           \
+    else if (mode == 1) BSRF_STG(1, NTT);      \
+    else BSRF_STG(3, NTT);                     \
+  } while (0)
+  if (NT == 4) BSRF_MODE(4);
+  else if (NT == 2) BSRF_MODE(2);
+  else BSRF_MODE(1);
+#undef BSRF_MODE
+#undef BSRF_STG
+#undef BSRF_LAUNCH
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_ell32(sw_engine* h, const EllOp& op, int mode, const cplxf* X, const cplxf* B,
+                        cplxf* Y, int nbp, int cat, cplxf w = cplxf{0.f, 0.f}) {
+  if (!op.set) return sw_fail(h, "operator not set");
+  if (op.bsr_KS > 0 && (mode == 0 || mode == 1 || mode == 3) && op.bsr_vals32)
+    return launch_bsr32(h, op, mode, X, B, Y, nbp, cat, w);
+  if (!op.cols || !op.vals32)
+    return sw_fail(h, "internal: complex64 mirror of a grouped-ELL operator missing");
+  dim3 grid((op.ngroups + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, nbp / 64);
+  LaunchScope ls(h, cat);
+  const int* ord = h->ell_order ? op.order : nullptr;
+#define ELLF_CASE(GG)                                                                            \
+  case GG:                                                                                       \
+    if (mode == 0)                                                                               \
+      hipLaunchKernelGGL((swk::k_ell<GG, 0, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream,         \
+                         (const int*)op.cols, (const cplxf*)op.vals32, op.K, op.ngroups, ord, X, B, Y, nbp, w); \
+    else if (mode == 1)                                                                          \
+      hipLaunchKernelGGL((swk::k_ell<GG, 1, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream,         \
+                         (const int*)op.cols, (const cplxf*)op.vals32, op.K, op.ngroups, ord, X, B, Y, nbp, w); \
+    else if (mode == 2)                                                                          \
+      hipLaunchKernelGGL((swk::k_ell<GG, 2, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream,         \
+                         (const int*)op.cols, (const cplxf*)op.vals32, op.K, op.ngroups, ord, X, B, Y, nbp, w); \
+    else                                                                                         \
+      hipLaunchKernelGGL((swk::k_ell<GG, 3, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream,         \
+                         (const int*)op.cols, (const cplxf*)op.vals32, op.K, op.ngroups, ord, X, B, Y, nbp, w); \
+    break;
+  switch (op.G) {
+    ELLF_CASE(1)
+    ELLF_CASE(2)
+    ELLF_CASE(4)
+    ELLF_CASE(8)
+    ELLF_CASE(16)
+    default:
+      return sw_fail(h, "unsupported ELL group size %d", op.G);
+  }
+#undef ELLF_CASE
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+// even-odd post-smoothing of the stencil level in complex64 (eo_smooth's twin)
+static int eo_smooth32(sw_engine* h, Level& lv, const cplxf* Bin, cplxf* start, cplxf* other, cplxf* Xout,
+                       int nbp) {
+  swk::StencilArgsT<cplxf> a;
+  a.L = lv.L;
+  a.Vh = lv.L * lv.L / 2;
+  a.diag = (float)(4.0 + lv.mass);
+  a.U1 = lv.U1f;
+  a.U2 = lv.U2f;
+  a.nbp = nbp;
+  a.nt_store = 0;
+  a.tile_w = lv.L;
+  // five lattice rows (1 KiB per site and 64-probe chunk, half the sites) must fit an XCD's L2
+  if (lv.L > 512) a.tile_w = (lv.L % 512 == 0) ? 512 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
+  a.w = cplxf{0.f, 0.f};
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  const float di = (float)(1.0 / (4.0 + lv.mass));
+  cplxf* bp = lv.r32;
+  {
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<0, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0f,
+                       di, bpc);
+    KLAUNCH_CHECK();
+  }
+  cplxf* cur = start;
+  cplxf* nxt = other;
+  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+    a.w = cplxf{(float)lv.w_eo[k].real(), (float)lv.w_eo[k].imag()};
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_schur_step<cplxf>), grid, dim3(SW_BLOCK), 0, h->stream, (const cplxf*)cur,
+                       (const cplxf*)bp, nxt, a, bpc);
+    KLAUNCH_CHECK();
+    std::swap(cur, nxt);
+  }
+  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
+  {
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<1, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream, Bin,
+                       (const cplxf*)Xout, Xout, a, di, di, bpc);
+    KLAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int vcycle32(sw_engine* h, Hier& H, int l, const cplxf* Bin, cplxf* Xout, int nbp) {
+  const int last = H.nlevels - 1;
+  if (l == last) {
+    if (!H.cinv.set) return sw_fail(h, "coarsest inverse not set");
+    return launch_ell32(h, H.cinv, 0, Bin, nullptr, Xout, nbp, T_COARSEST);
+  }
+  Level& lv = H.lv[l];
+  Level& lc = H.lv[l + 1];
+  if (!lv.rich || lv.gm_m > 0 || !lv.w_pre.empty() || lv.kcycle > 0)
+    return sw_fail(h, "precond_f32 supports fixed-polynomial post-smoothing cycles without K-cycles only "
+                      "(level %d is configured otherwise)", l);
+  SWCHK(ensure_level_ws32(h, lv, nbp));
+  SWCHK(ensure_level_ws32(h, lc, nbp));
+  if (!lv.P.set || !lv.R.set) return sw_fail(h, "transfer operators of level %d not set", l);
+  SWCHK(launch_ell32(h, lv.R, 0, Bin, nullptr, lc.b32, nbp, T_R));
+  SWCHK(vcycle32(h, H, l + 1, lc.b32, lc.x32, nbp));
+  const cplxf z{0.f, 0.f};
+  if (!lv.stencil && !lv.w_eo.empty() && lv.eo_op[0].set) {
+    const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+    cplxf* cur = odd_steps ? lv.t32 : Xout;
+    cplxf* nxt = odd_steps ? Xout : lv.t32;
+    SWCHK(launch_ell32(h, lv.P, 0, lc.x32, nullptr, cur, nbp, T_P));
+    SWCHK(launch_bsr32(h, lv.eo_op[1], 1, Bin, Bin, lv.r32, nbp, T_MVM, z));
+    for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+      SWCHK(launch_bsr32(h, lv.eo_op[0], 3, cur, lv.r32, nxt, nbp, T_MVM,
+                         cplxf{(float)lv.w_eo[k].real(), (float)lv.w_eo[k].imag()}));
+      std::swap(cur, nxt);
+    }
+    SWCHK(launch_bsr32(h, lv.eo_op[2], 0, Bin, nullptr, Xout, nbp, T_MVM, z));
+    return launch_bsr32(h, lv.eo_op[3], 1, Xout, Xout, Xout, nbp, T_MVM, z);
+  }
+  if (lv.stencil) {
+    if (lv.w_eo.empty())
+      return sw_fail(h, "precond_f32 needs the even-odd smoother on the stencil level (sw_set_eo_smoother)");
+    const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+    cplxf* start = odd_steps ? lv.t32 : Xout;
+    cplxf* other = odd_steps ? Xout : lv.t32;
+    SWCHK(launch_ell32(h, lv.P, 0, lc.x32, nullptr, start, nbp, T_P));
+    return eo_smooth32(h, lv, Bin, start, other, Xout, nbp);
+  }
+  // block level with the plain polynomial post-smoother: x <- x + w_k (b - A x)
+  const size_t npost = lv.w_post.size();
+  cplxf* cur = (npost % 2 == 0) ? Xout : lv.t32;
+  cplxf* nxt = (npost % 2 == 0) ? lv.t32 : Xout;
+  SWCHK(launch_ell32(h, lv.P, 0, lc.x32, nullptr, cur, nbp, T_P));
+  for (size_t k = 0; k < npost; ++k) {
+    SWCHK(launch_ell32(h, lv.A, 3, cur, Bin, nxt, nbp, T_MVM,
+                       cplxf{(float)lv.w_post[k].real(), (float)lv.w_post[k].imag()}));
+    std::swap(cur, nxt);
+  }
+  if (cur != Xout) return sw_fail(h, "internal: polynomial smoother ended in the wrong buffer");
+  return 0;
+}
+
+// can the cycle that starts at `level` run on the complex64 path?  (otherwise the fp64 cycle is used)
+static bool f32_capable(const Hier& H, int level) {
+  for (int l = level; l < H.nlevels - 1; ++l) {
+    const Level& lv = H.lv[l];
+    if (!lv.rich || lv.gm_m > 0 || !lv.w_pre.empty() || lv.kcycle > 0) return false;
+    if (lv.stencil && lv.w_eo.empty()) return false;
+  }
+  return level < H.nlevels - 1;
+}
+
+// the preconditioner as the fp64 solver sees it: Xout = (fp64) cycle32((complex64) Bin)
+static int vcycle_f32_boundary(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
+  SWCHK(ensure_f32(h, H));
+  Level& lv = H.lv[l];
+  SWCHK(ensure_level_ws32(h, lv, nbp));
+  const size_t cnt = (size_t)lv.n * nbp;
+  SWCHK(cast_vec(h, Bin, lv.i32, cnt, T_AXPY));
+  SWCHK(vcycle32(h, H, l, lv.i32, lv.o32, nbp));
+  return cast_vec(h, (const cplxf*)lv.o32, Xout, cnt, T_AXPY);
+}
+
+// ---------------------------------------------------------------------------------------------
 // batched right-preconditioned flexible GMRES(m) (MG.solve -> fgmres, multigrid.py:347-366);
 // one classical Gram-Schmidt pass per step (two with option cgs2), true-residual verification
 //  outer == true : restarted, converges every probe to tol (one host read-back per iteration)
@@ -1076,7 +1378,8 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       const cplx* vj = vt(j);
       cplx* zj = ws.Z + vec * j;
       cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
-      if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
+      if (precond && outer && h->precond_f32 && f32_capable(H, level)) SWCHK(vcycle_f32_boundary(h, H, level, vj, zj, nbp));
+      else if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
       else SWCHK(copy_vec(h, zj, vj, n, nbp));
       SWCHK(apply_op(h, lv, 0, zj, nullptr, w, nbp));
       PtrList pv;
@@ -1285,6 +1588,9 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(dev_free(h, lv.rowmap));
     SWCHK(dev_free(h, lv.b)); SWCHK(dev_free(h, lv.x)); SWCHK(dev_free(h, lv.r));
     SWCHK(dev_free(h, lv.t));
+    SWCHK(dev_free(h, lv.U1f)); SWCHK(dev_free(h, lv.U2f));
+    SWCHK(dev_free(h, lv.b32)); SWCHK(dev_free(h, lv.x32)); SWCHK(dev_free(h, lv.r32));
+    SWCHK(dev_free(h, lv.t32)); SWCHK(dev_free(h, lv.i32)); SWCHK(dev_free(h, lv.o32));
     SWCHK(free_krylov(h, lv.kws));
     SWCHK(free_krylov(h, lv.sws));
     SWCHK(free_krylov(h, lv.gws));
@@ -1295,6 +1601,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
   SWCHK(free_op(h, H.cinv));
   H.nlevels = nlevels;
   H.ready = false;
+  H.f32_valid = false;
   if (hid == 0) {
     // everything that was sized or indexed by the previous definition of the reference
     // hierarchy: deflation vectors, permutations, rhs maps, probe slots and the probe workspace
@@ -1325,6 +1632,7 @@ int sw_set_lattice(sw_engine* h, int hid, int L, double mass, const double* U1, 
   if (!U1 || !U2) return sw_fail(h, "null link arrays");
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[hid].lv[0];
+  h->hier[hid].f32_valid = false;
   lv.stencil = true;
   lv.L = L;
   lv.mass = mass;
@@ -1350,6 +1658,7 @@ int sw_set_csr(sw_engine* h, int hid, int level, int n, const int64_t* indptr,
   if (n <= 0 || !indptr || !indices || !data) return sw_fail(h, "sw_set_csr: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[hid].lv[level];
+  h->hier[hid].f32_valid = false;
   if (lv.stencil) {
     if (lv.n != n) return sw_fail(h, "sw_set_csr: n=%d differs from the lattice size %d", n, lv.n);
     return 0;  // the stencil is the operator; the CSR is redundant
@@ -1366,6 +1675,7 @@ int sw_set_transfer(sw_engine* h, int hid, int level, int n_f, int n_c, const in
                     const int32_t* indices, const double* data) {
   SWCHK(check_hier(h, hid, level, false));
   Hier& H = h->hier[hid];
+  H.f32_valid = false;
   if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d to transfer to", level);
   if (!indptr || !indices || !data) return sw_fail(h, "sw_set_transfer: null arrays");
   HIPCHK(hipSetDevice(h->device));
@@ -1407,6 +1717,7 @@ int sw_set_transfer(sw_engine* h, int hid, int level, int n_f, int n_c, const in
 int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense) {
   SWCHK(check_hier(h, hid, 0, false));
   Hier& H = h->hier[hid];
+  H.f32_valid = false;
   Level& lv = H.lv[H.nlevels - 1];
   if (!dense || n <= 0) return sw_fail(h, "sw_set_coarsest_inv: bad arguments");
   if (lv.n == 0) lv.n = n;
@@ -1521,6 +1832,7 @@ int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, co
                       int G, int K, const int32_t* pcols, const int64_t* pmap, const int32_t* porder) {
   SWCHK(check_hier(h, hid, level, false));
   Hier& H = h->hier[hid];
+  H.f32_valid = false;
   if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d", level);
   if (!blk_rows || !pcols || !pmap || nblocks <= 0 || rpb <= 0) return sw_fail(h, "bad arguments");
   if (rpb > 256) return sw_fail(h, "aggregate blocks of %d rows exceed the QR kernel's 256", rpb);
@@ -1608,6 +1920,7 @@ int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, co
 int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* nbr) {
   SWCHK(check_hier(h, hid, level, false));
   Hier& H = h->hier[hid];
+  H.f32_valid = false;
   if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d", level);
   if (!nbr || Lc < 4 || (Lc & 3)) return sw_fail(h, "coarse lattice extent %d must be a multiple of 4", Lc);
   if (!h->use_mfma || !h->mfma_ops) return sw_fail(h, "the device setup needs use_mfma = mfma_ops = 1");
@@ -1696,6 +2009,7 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   SWCHK(check_hier(h, hid, 0, false));
   HIPCHK(hipSetDevice(h->device));
   Hier& H = h->hier[hid];
+  H.f32_valid = false;
   Level& lv = H.lv[H.nlevels - 1];
   const EllOp& A = lv.A;
   if (H.nlevels < 2 || !A.set || A.bsr_KS <= 0) return sw_fail(h, "coarsest level has no block-row operator");
@@ -1789,6 +2103,7 @@ int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int 
   if (which < 0 || which > 3) return sw_fail(h, "even-odd operator index %d out of [0,3]", which);
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[hid].lv[level];
+  h->hier[hid].f32_valid = false;
   if (lv.stencil || lv.n <= 0 || lv.n % 16) return sw_fail(h, "level %d is not a block level", level);
   if (RT <= 0 || KS <= 0 || (KS & 3) || !tmap || !kcol || !vals) return sw_fail(h, "bad arguments");
   const int tiles = lv.n / 16;
@@ -1839,6 +2154,7 @@ int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const doubl
 int sw_hier_end(sw_engine* h, int hid) {
   SWCHK(check_hier(h, hid, 0, false));
   Hier& H = h->hier[hid];
+  H.f32_valid = false;
   for (int l = 0; l < H.nlevels; ++l) {
     Level& lv = H.lv[l];
     if (lv.n <= 0) return sw_fail(h, "level %d has no size", l);
@@ -1929,6 +2245,24 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "inner_cgs2") == 0) {
     h->inner_cgs2 = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "precond_f32") == 0) {
+    h->precond_f32 = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "f32_tiles") == 0) {
+    const int v = (int)value;
+    if (v != 0 && v != 1 && v != 2 && v != 4) return sw_fail(h, "f32_tiles must be 0, 1, 2 or 4");
+    h->f32_tiles = v;
+    return 0;
+  }
+  if (std::strcmp(name, "f32_stages") == 0) {
+    h->f32_stages = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "f32_dense_stages") == 0) {
+    h->f32_dense_stages = (int)value;
     return 0;
   }
   if (std::strcmp(name, "verify") == 0) {
@@ -2106,7 +2440,8 @@ int sw_vcycle(sw_engine* h, int hid, int level0, int nb, const double* B, double
   cplx *a, *b;
   SWCHK(io_vectors(h, lv, nbp, &a, &b));
   SWCHK(pack_host(h, lv, nb, B, a, nbp));
-  SWCHK(vcycle(h, H, level0, a, b, nbp));
+  if (h->precond_f32 && f32_capable(H, level0)) SWCHK(vcycle_f32_boundary(h, H, level0, a, b, nbp));
+  else SWCHK(vcycle(h, H, level0, a, b, nbp));
   return unpack_host(h, lv, nb, b, X, nbp);
 }
 

@@ -45,6 +45,36 @@ __device__ __forceinline__ void cfmac(cplx& acc, cplx a, cplx b) {
 }
 // i*a
 __device__ __forceinline__ cplx cmuli(cplx a) { return cmake(-a.y, a.x); }
+__device__ __forceinline__ double rfma(double a, double b, double c) { return fma(a, b, c); }
+
+// complex64 twins (single-precision preconditioner): same formulae on float2
+typedef float2 cplxf;
+__device__ __forceinline__ float rfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ cplxf cmake(float a, float b) { cplxf r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ cplxf cadd(cplxf a, cplxf b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplxf csub(cplxf a, cplxf b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplxf cmul(cplxf a, cplxf b) {
+  return cmake(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplxf cmulc(cplxf a, cplxf b) {
+  return cmake(fmaf(a.x, b.x, a.y * b.y), fmaf(a.x, b.y, -a.y * b.x));
+}
+__device__ __forceinline__ void cfma(cplxf& acc, cplxf a, cplxf b) {
+  acc.x = fmaf(a.x, b.x, acc.x);
+  acc.x = fmaf(-a.y, b.y, acc.x);
+  acc.y = fmaf(a.x, b.y, acc.y);
+  acc.y = fmaf(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ cplxf cmuli(cplxf a) { return cmake(-a.y, a.x); }
+template <class C> struct real_of;
+template <> struct real_of<cplx> { typedef double type; };
+template <> struct real_of<cplxf> { typedef float type; };
+template <class C> __device__ __forceinline__ C czero() {
+  C r;
+  r.x = 0;
+  r.y = 0;
+  return r;
+}
 
 // Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH, Workgroup dispatch); this
 // bijective remap hands each XCD one contiguous range of logical blocks so that neighbouring
@@ -61,17 +91,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 // MODE 0: Y = A X      MODE 1: Y = B - A X      MODE 2: Y = X + w (B - A X)  (one fused
 // Richardson/polynomial-smoother step: 3 vector passes, no inner products)
 // ------------------------------------------------------------------------------------------
-struct StencilArgs {
+template <class C>
+struct StencilArgsT {
   int L;          // lattice extent (even)
   int Vh;         // L*L/2
-  double diag;    // 4 + mass
-  const cplx* U1; // [L*L] site index y*L+x
-  const cplx* U2;
+  typename real_of<C>::type diag;    // 4 + mass
+  const C* U1;    // [L*L] site index y*L+x
+  const C* U2;
   int nbp;
   int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
-  cplx w;              // MODE 2 relaxation weight
+  C w;                 // MODE 2 relaxation weight
   int nt_store;        // non-temporal output stores
 };
+typedef StencilArgsT<cplx> StencilArgs;
 
 __device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
   // row of spin 0 of site (x,y) in the even-odd layout; spin 1 is the next row
@@ -178,14 +210,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
 // from the 13-point neighbourhood of X and the 5-point neighbourhood of B (all L2-served), so
 // two polynomial steps cost 3 HBM vector passes instead of 6.  One wave = one site x 64 probes.
 // ------------------------------------------------------------------------------------------
-struct Site2 {
-  cplx s0, s1;
+template <class C>
+struct SiteT {
+  C s0, s1;
 };
+typedef SiteT<cplx> Site2;
 
-__device__ __forceinline__ Site2 ld_site(const cplx* __restrict__ base, int x, int y, int L, int Vh,
-                                         int nbp) {
+template <class C>
+__device__ __forceinline__ SiteT<C> ld_site(const C* __restrict__ base, int x, int y, int L, int Vh,
+                                            int nbp) {
   const size_t r = eo_row(x, y, L, Vh);
-  Site2 v;
+  SiteT<C> v;
   v.s0 = base[r * nbp];
   v.s1 = base[(r + 1) * nbp];
   return v;
@@ -376,22 +411,22 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step_lds(const cplx* __re
 // ------------------------------------------------------------------------------------------
 // contribution of one hop to a 2-spinor: dir 0:+x (1-s1) u psi, 1:-x (1+s1) conj(u) psi,
 // 2:+y (1-s2) u psi, 3:-y (1+s2) conj(u) psi   (u = the link the hop runs along)
-template <int DIR>
-__device__ __forceinline__ void hop_acc(Site2& acc, cplx u, Site2 psi) {
+template <int DIR, class C>
+__device__ __forceinline__ void hop_acc(SiteT<C>& acc, C u, SiteT<C> psi) {
   if (DIR == 0) {
-    const cplx t = cmul(u, csub(psi.s0, psi.s1));
+    const C t = cmul(u, csub(psi.s0, psi.s1));
     acc.s0 = cadd(acc.s0, t);
     acc.s1 = csub(acc.s1, t);
   } else if (DIR == 1) {
-    const cplx t = cmulc(u, cadd(psi.s0, psi.s1));
+    const C t = cmulc(u, cadd(psi.s0, psi.s1));
     acc.s0 = cadd(acc.s0, t);
     acc.s1 = cadd(acc.s1, t);
   } else if (DIR == 2) {
-    const cplx t = cmul(u, cadd(psi.s0, cmuli(psi.s1)));
+    const C t = cmul(u, cadd(psi.s0, cmuli(psi.s1)));
     acc.s0 = cadd(acc.s0, t);
     acc.s1 = csub(acc.s1, cmuli(t));
   } else {
-    const cplx t = cmulc(u, csub(psi.s0, cmuli(psi.s1)));
+    const C t = cmulc(u, csub(psi.s0, cmuli(psi.s1)));
     acc.s0 = cadd(acc.s0, t);
     acc.s1 = cadd(acc.s1, cmuli(t));
   }
@@ -414,11 +449,12 @@ __device__ __forceinline__ void eo_site(int it, int q, int L, int tw, int& x, in
 // out(n) = alpha * Uv(n) + beta * (H src)(n)  on the sites n of parity Q; src on the other parity.
 //   Q = 0, Uv = src = B, alpha = 1, beta = 1/D :  b'_e = b_e + H_eo b_o / D
 //   Q = 1, Uv = B, src = X, alpha = beta = 1/D:  x_o  = (b_o + H_oe x_e) / D
-template <int Q>
-__global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const cplx* __restrict__ Uv,
-                                                     const cplx* __restrict__ src,
-                                                     cplx* __restrict__ out, StencilArgs a,
-                                                     double alpha, double beta,
+template <int Q, class C>
+__global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const C* __restrict__ Uv,
+                                                     const C* __restrict__ src,
+                                                     C* __restrict__ out, StencilArgsT<C> a,
+                                                     typename real_of<C>::type alpha,
+                                                     typename real_of<C>::type beta,
                                                      int blocks_per_chunk) {
   const int bb = xcd_remap(blockIdx.x, gridDim.x);
   const int chunk = bb / blocks_per_chunk;
@@ -431,25 +467,28 @@ __global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const cplx* __restrict__ Uv
   int x, y;
   eo_site(sh, Q, L, a.tile_w, x, y);
   const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
-  const cplx* S = src + col;
-  Site2 acc;
-  acc.s0 = cmake(0.0, 0.0);
+  const C* S = src + col;
+  SiteT<C> acc;
+  acc.s0 = czero<C>();
   acc.s1 = acc.s0;
   hop_acc<0>(acc, a.U1[y * L + x], ld_site(S, xp, y, L, Vh, nbp));
   hop_acc<1>(acc, a.U1[y * L + xm], ld_site(S, xm, y, L, Vh, nbp));
   hop_acc<2>(acc, a.U2[y * L + x], ld_site(S, x, yp, L, Vh, nbp));
   hop_acc<3>(acc, a.U2[ym * L + x], ld_site(S, x, ym, L, Vh, nbp));
   const size_t r = eo_row(x, y, L, Vh);
-  const cplx u0 = Uv[r * nbp + col], u1 = Uv[(r + 1) * nbp + col];
-  out[r * nbp + col] = cmake(fma(alpha, u0.x, beta * acc.s0.x), fma(alpha, u0.y, beta * acc.s0.y));
-  out[(r + 1) * nbp + col] = cmake(fma(alpha, u1.x, beta * acc.s1.x), fma(alpha, u1.y, beta * acc.s1.y));
+  const C u0 = Uv[r * nbp + col], u1 = Uv[(r + 1) * nbp + col];
+  out[r * nbp + col] = cmake(rfma(alpha, u0.x, beta * acc.s0.x), rfma(alpha, u0.y, beta * acc.s0.y));
+  out[(r + 1) * nbp + col] = cmake(rfma(alpha, u1.x, beta * acc.s1.x), rfma(alpha, u1.y, beta * acc.s1.y));
 }
 
 // Y_e = X_e + w (Bp_e - S X_e),  S = D - H_eo H_oe / D : both hops in one kernel (even sites only)
-__global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const cplx* __restrict__ X,
-                                                         const cplx* __restrict__ Bp,
-                                                         cplx* __restrict__ Y, StencilArgs a,
+template <class C>
+__global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X,
+                                                         const C* __restrict__ Bp,
+                                                         C* __restrict__ Y, StencilArgsT<C> a,
                                                          int blocks_per_chunk) {
+  typedef SiteT<C> Site2;
+  typedef typename real_of<C>::type real;
   const int bb = xcd_remap(blockIdx.x, gridDim.x);
   const int chunk = bb / blocks_per_chunk;
   const int sg = bb % blocks_per_chunk;
@@ -462,18 +501,18 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const cplx* __restrict_
   eo_site(sh, 0, L, a.tile_w, x, y);
   const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
   const int xpp = wrap_p(xp, L), xmm = wrap_m(xm, L), ypp = wrap_p(yp, L), ymm = wrap_m(ym, L);
-  const cplx* Xc = X + col;
+  const C* Xc = X + col;
   // the eight even sites at distance 2
   const Site2 e20 = ld_site(Xc, xpp, y, L, Vh, nbp), em20 = ld_site(Xc, xmm, y, L, Vh, nbp);
   const Site2 e02 = ld_site(Xc, x, ypp, L, Vh, nbp), e0m2 = ld_site(Xc, x, ymm, L, Vh, nbp);
   const Site2 ePP = ld_site(Xc, xp, yp, L, Vh, nbp), ePM = ld_site(Xc, xp, ym, L, Vh, nbp);
   const Site2 eMP = ld_site(Xc, xm, yp, L, Vh, nbp), eMM = ld_site(Xc, xm, ym, L, Vh, nbp);
-  const cplx* U1 = a.U1;
-  const cplx* U2 = a.U2;
+  const C* U1 = a.U1;
+  const C* U2 = a.U2;
 #define SW_U1(xx, yy) U1[(yy) * L + (xx)]
 #define SW_U2(xx, yy) U2[(yy) * L + (xx)]
   Site2 z;
-  z.s0 = cmake(0.0, 0.0);
+  z.s0 = czero<C>();
   z.s1 = z.s0;
   // t(o) = sum over the hops into the odd neighbour o that do not come from n; then the hop o -> n
   Site2 t = z;                                          // o = n + x
@@ -500,13 +539,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const cplx* __restrict_
 #undef SW_U1
 #undef SW_U2
   const size_t r = eo_row(x, y, L, Vh);
-  const double d = a.diag, di = 1.0 / a.diag;
-  const cplx c0 = Xc[r * nbp], c1 = Xc[(r + 1) * nbp];
-  const cplx q0 = Bp[r * nbp + col], q1 = Bp[(r + 1) * nbp + col];
+  const real d = a.diag, di = (real)1 / a.diag;
+  const C c0 = Xc[r * nbp], c1 = Xc[(r + 1) * nbp];
+  const C q0 = Bp[r * nbp + col], q1 = Bp[(r + 1) * nbp + col];
   // residual of S: b' - (D x - acc / D)
-  const cplx r0 = cmake(q0.x - d * c0.x + di * acc.s0.x, q0.y - d * c0.y + di * acc.s0.y);
-  const cplx r1 = cmake(q1.x - d * c1.x + di * acc.s1.x, q1.y - d * c1.y + di * acc.s1.y);
-  cplx o0 = c0, o1 = c1;
+  const C r0 = cmake(q0.x - d * c0.x + di * acc.s0.x, q0.y - d * c0.y + di * acc.s0.y);
+  const C r1 = cmake(q1.x - d * c1.x + di * acc.s1.x, q1.y - d * c1.y + di * acc.s1.y);
+  C o0 = c0, o1 = c1;
   cfma(o0, a.w, r0);
   cfma(o1, a.w, r1);
   Y[r * nbp + col] = o0;
@@ -522,13 +561,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const cplx* __restrict_
 // MODE 0: Y = A X      MODE 1: Y = B - A X      MODE 2: Y = B + A X
 // MODE 3: Y = X + w (B - A X)   (square operators only)
 // ------------------------------------------------------------------------------------------
-template <int G, int MODE>
+template <int G, int MODE, class C = cplx>
 __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
-                                                  const cplx* __restrict__ vals, int K,
+                                                  const C* __restrict__ vals, int K,
                                                   int ngroups, const int* __restrict__ order,
-                                                  const cplx* __restrict__ X,
-                                                  const cplx* __restrict__ B,
-                                                  cplx* __restrict__ Y, int nbp, cplx w) {
+                                                  const C* __restrict__ X,
+                                                  const C* __restrict__ B,
+                                                  C* __restrict__ Y, int nbp, C w) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int bx = xcd_remap(blockIdx.x, gridDim.x);   // contiguous row band per XCD (L2 reuse)
@@ -537,26 +576,26 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
   const int grp = order ? __builtin_amdgcn_readfirstlane(order[slot]) : slot;
   const size_t col = (size_t)blockIdx.y * 64 + lane;
   const int* c = cols + (size_t)grp * K;
-  const cplx* v = vals + (size_t)grp * K * G;
-  cplx acc[G];
+  const C* v = vals + (size_t)grp * K * G;
+  C acc[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = cmake(0.0, 0.0);
-  const cplx* Xc = X + col;
+  for (int g = 0; g < G; ++g) acc[g] = czero<C>();
+  const C* Xc = X + col;
 #pragma unroll 4
   for (int k = 0; k < K; ++k) {
     const int j = c[k];
-    const cplx x = Xc[(size_t)j * nbp];
+    const C x = Xc[(size_t)j * nbp];
 #pragma unroll
     for (int g = 0; g < G; ++g) cfma(acc[g], v[(size_t)k * G + g], x);
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const size_t row = (size_t)grp * G + g;
-    cplx o = acc[g];
+    C o = acc[g];
     if (MODE == 1) o = csub(B[row * nbp + col], o);
     if (MODE == 2) o = cadd(B[row * nbp + col], o);
     if (MODE == 3) {
-      cplx t = X[row * nbp + col];
+      C t = X[row * nbp + col];
       cfma(t, w, csub(B[row * nbp + col], o));
       o = t;
     }
@@ -787,6 +826,122 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma_sk(const cplx* __restrict
       im[t][r] += red[0][t * 8 + 4 + r][lane] + red[1][t * 8 + 4 + r][lane] + red[2][t * 8 + 4 + r][lane];
     }
   bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-precision twin of the block-row kernel (f32 preconditioner): v_mfma_f32_16x16x4_f32 runs
+// at twice the fp64 matrix rate on gfx950 (157 vs 78.6 TFLOP/s) and every stream is half as wide.
+// X and Y are complex64 [n][nbp]; a lane holds ONE complex probe value of a 4-row k-step
+// (lane l: row l>>4 of the step, probe l&15 of the tile: 16 lanes x 8 B = one 128-B segment per row),
+// so the real and imaginary parts are separate B operands and no lane exchange is needed:
+//   Re Y += Re(A) Re(X) + (-Im A) Im(X),   Im Y += Re(A) Im(X) + Im(A) Re(X)     (4 MFMAs per tile)
+// C/D of the f32 form: lane l holds rows 4 (l>>4) + r, r < 4, of column l&15 (cdna_hip_programming.md).
+// A is packed exactly as for the fp64 kernel (same kcol, same lane order), converted to float2.
+// One wave = one 16-row tile x NT tiles of 16 probes.  MODE as k_bsr_mfma.
+// ------------------------------------------------------------------------------------------
+typedef float sw_float4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int NT, int STG>
+__global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma_f32(const cplxf* __restrict__ Ap,
+                                                           const int* __restrict__ kcol, int KS,
+                                                           int RT, const cplxf* __restrict__ X,
+                                                           const cplxf* __restrict__ B,
+                                                           cplxf* __restrict__ Y, int nbp, cplxf w,
+                                                           int map, const int* __restrict__ tmap) {
+  const int lane = threadIdx.x & 63;
+  // 1-D grid of RB x NC blocks, ordered as k_bsr_mfma's map 0 (chunk-major, XCD bands of row blocks)
+  // or map 1 (XCD band of row blocks, the chunks of a row block adjacent in time)
+  const int RB = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const int NC = gridDim.x / RB;
+  int bx, cy;
+  if (map == 0 || (RB & 7)) {
+    cy = blockIdx.x / RB;
+    bx = xcd_remap(blockIdx.x - cy * RB, RB);
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, RBx = RB >> 3;
+    cy = j % NC;
+    bx = xcd * RBx + j / NC;
+  }
+  const int rt = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (rt >= RT) return;
+  const int c0 = cy * (16 * NT);                    // first probe of this chunk
+  const cplxf* a = Ap + (size_t)rt * KS * 64 + lane;
+  const int* kc = kcol + (size_t)rt * KS;           // wave-uniform -> scalar loads
+  const cplxf* b = X + (size_t)(lane >> 4) * nbp + c0 + (lane & 15);
+  sw_float4 re[NT], im[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    re[t] = sw_float4{0.f, 0.f, 0.f, 0.f};
+    im[t] = re[t];
+  }
+#define SW_BSRF_LOAD(M_, X_, KSI)                               \
+  {                                                             \
+    M_ = a[(size_t)(KSI) * 64];                                 \
+    const cplxf* bk_ = b + (size_t)kc[(KSI)] * nbp;             \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) X_[t] = bk_[t * 16]; \
+  }
+  // the two accumulations into re[t] (and im[t]) are 2 NT MFMAs apart: beyond the 40-cycle
+  // dependent latency of the instruction for every NT >= 1
+#define SW_BSRF_MFMA(M_, X_)                                                              \
+  {                                                                                       \
+    const float nay_ = -M_.y;                                                             \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                      \
+      re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(M_.x, X_[t].x, re[t], 0, 0, 0);        \
+      im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(M_.x, X_[t].y, im[t], 0, 0, 0);        \
+    }                                                                                     \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                      \
+      re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(nay_, X_[t].y, re[t], 0, 0, 0);        \
+      im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(M_.y, X_[t].x, im[t], 0, 0, 0);        \
+    }                                                                                     \
+  }
+  cplxf mm[STG];
+  cplxf xx[STG][NT];
+#pragma unroll
+  for (int s = 0; s < STG; ++s) SW_BSRF_LOAD(mm[s], xx[s], (s < KS ? s : 0));
+  for (int ks = 0; ks < KS; ks += STG) {
+#pragma unroll
+    for (int s = 0; s < STG; ++s) {
+      if (ks + s < KS) {                                            // KS need not divide by STG
+        const int kn = (ks + s + STG < KS) ? ks + s + STG : ks + s;   // tail: harmless re-load
+        __builtin_amdgcn_sched_barrier(0);
+        SW_BSRF_MFMA(mm[s], xx[s]);
+        __builtin_amdgcn_sched_barrier(0);
+        SW_BSRF_LOAD(mm[s], xx[s], kn);
+      }
+    }
+  }
+#undef SW_BSRF_LOAD
+#undef SW_BSRF_MFMA
+  const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t row = (size_t)ot * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const size_t off = row * nbp + c0 + t * 16 + (lane & 15);
+      cplxf y = cmake(re[t][r], im[t][r]);
+      if (MODE == 1) y = csub(B[off], y);
+      if (MODE == 3) {
+        cplxf o = X[off];
+        cfma(o, w, csub(B[off], y));
+        y = o;
+      }
+      Y[off] = y;
+    }
+  }
+}
+
+// precision boundary of the single-precision preconditioner: dst = (CO) src, element-wise
+template <class CI, class CO>
+__global__ __launch_bounds__(SW_BLOCK) void k_cast(const CI* __restrict__ src, CO* __restrict__ dst,
+                                                   size_t count) {
+  const size_t i = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const CI v = src[i];
+  CO o;
+  o.x = (typename real_of<CO>::type)v.x;
+  o.y = (typename real_of<CO>::type)v.y;
+  dst[i] = o;
 }
 
 // ------------------------------------------------------------------------------------------

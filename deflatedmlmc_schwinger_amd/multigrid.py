@@ -217,6 +217,7 @@ class MG:
             for eng in self.engines:
                 info = setup_gpu.device_solver_hierarchy(eng, lat, cfg, SOLVER_HID)
                 eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
+                eng.set_option("precond_f32", 1 if cfg.get("precond_precision", "f64") == "f32" else 0)
             self._have_solver_hier = True
             self.solver_hier = None
             self.solver_testvectors = None
@@ -282,6 +283,7 @@ class MG:
             eng.set_coarsest_inv(SOLVER_HID, sh["coarsest_inv"])
             eng.hier_end(SOLVER_HID)
             eng.set_solver(int(cfg.get("restart", 24)), SOLVER_HID)
+            eng.set_option("precond_f32", 1 if cfg.get("precond_precision", "f64") == "f32" else 0)
         Lc = L
         for i in range(1, nl - 1):
             Lc //= cfg["coarsening"][i - 1][0]

@@ -938,3 +938,42 @@ def test_even_odd_smoother_on_block_levels_matches_model(p128):
         assert int(its.max()) < 40
     finally:
         p.mg.upload_solver_hierarchy(None)
+
+
+def test_single_precision_preconditioner_keeps_fp64_results(p128):
+    """Option precond_f32 (cfg key precond_precision = "f32"): the multigrid cycle inside the fp64
+    flexible GMRES runs in complex64 (k_bsr_mfma_f32, k_schur_step<float2>, k_ell<.., float2>).
+    The cycle itself equals the fp64 cycle to single-precision round-off; the converged solves are fp64:
+    per-probe estimates against the sparse-LU oracle at the north-star tolerance 1e-10, with the
+    iteration count of the fp64 preconditioner (+-2)."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    p = p128
+    base = dict(hierarchy.DEFAULT_SOLVER_CFG, coarsening=[(4, 8), (2, 8), (2, 8)],
+                cycle=[(0, 4, 0), (0, 3, 0), (0, 5, 0)], eo_levels=[0, 1, 2])
+    n = p.A.shape[0]
+    np.random.seed(4242)
+    probes = utils.draw_probes(70, n)
+    lu = p.lu_solver(0)
+    PT = p.levels[0].Pperm.transpose()
+    try:
+        p.mg.upload_solver_hierarchy(base)
+        tvs = p.mg.solver_testvectors
+        X64 = {}
+        for level0 in (2, 1, 0):
+            B = _rand((p.mg.solver_hier["A"][level0].shape[0], 70), 23 + level0)
+            X64[level0] = (B, p.eng.vcycle(SOLVER_HID, level0, B.T.copy()))
+        _, its64, _ = p.eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+        p.mg.upload_solver_hierarchy(dict(base, precond_precision="f32"), testvectors=tvs)
+        for level0 in (2, 1, 0):
+            B, ref = X64[level0]
+            X = p.eng.vcycle(SOLVER_HID, level0, B.T.copy())
+            err = _relerr(X, ref)
+            assert 1e-9 < err < 2e-5, (level0, err)      # single precision, and really single precision
+        ests, its, _ = p.eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+        for k in range(0, 70, 7):
+            ref_e = rp.hutch_probe(probes[k].astype(np.complex128), lu, p.Ux, PT)
+            assert abs(ests[k] - ref_e) / abs(ref_e) < 1e-10
+        assert abs(int(its.max()) - int(its64.max())) <= 2, (its.max(), its64.max())
+    finally:
+        p.eng.set_option("precond_f32", 0)
+        p.mg.upload_solver_hierarchy(None)

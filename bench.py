@@ -58,6 +58,8 @@ def parse():
                          "2-level multigrid 32768 -> 8192 built with the reference's aggregation "
                          "(32-row aggregates, 4 test vectors x 2), dense 8192^2 coarse inverse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-line", action="store_true",
+                    help="skip the secondary measurement with the single-precision preconditioner")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
     ap.add_argument("--engine-opts", type=str, default=os.environ.get("SW_ENGINE_OPTS", ""),
@@ -287,6 +289,38 @@ def run(args):
             step(args.warmup + i, False, 1 + i)
     elapsed_pcie = timed(pcie)
 
+    # ---- secondary: the same K steps with the multigrid cycle in single precision (complex64 on the
+    # f32 matrix cores) INSIDE the fp64 flexible GMRES -- residuals, orthogonalisation and the
+    # true-residual verification stay fp64, every probe converges to the same tol.  Reported next
+    # to `value`, never as `value` (which is the all-fp64 path).
+    f32_line = None
+    scfg_used = (mg.solver_info or {}).get("cfg") if mg.solver_info else None
+    if scfg_used and swhier.f32_capable(scfg_used) and not args.no_f32_line:
+        for e_ in engs:
+            e_.set_option("precond_f32", 1)
+        step(args.warmup + args.steps)                      # builds the complex64 mirrors
+        its32 = []
+        ref_chk = []
+
+        def f32_steps():
+            for s in range(args.warmup, args.warmup + args.steps):
+                ests, itf, stats = step(s)
+                its32.append(int(itf.max()))
+                ref_chk.append(stats)
+        elapsed_f32 = timed(f32_steps)
+        for e_ in engs:
+            e_.set_option("precond_f32", 0)
+        tot32 = np.sum(ref_chk, axis=0)
+        f32_line = {"value": world * ne * args.steps * nb / elapsed_f32,
+                    "ms_per_step": 1e3 * elapsed_f32 / args.steps,
+                    "outer_iterations_max": max(its32),
+                    # same probes as the fp64 steps: the sums of the per-probe estimates agree to
+                    # the solver tolerance
+                    "rel_diff_of_estimate_sum_vs_fp64": float(abs(tot32[0] - total[0]) / abs(total[0]))
+                    if total[0] != 0 else None,
+                    "note": "multigrid preconditioner in complex64 (k_bsr_mfma_f32, k_schur_step<float2>) "
+                            "inside the fp64 FGMRES; tol %.0e reached by every probe in fp64" % args.tol}
+
     # ---- generation alone (device time of k_mt_jump + k_mt_generate per batch) ------------------
     def gen_only():
         for i in range(nres):
@@ -384,6 +418,7 @@ def run(args):
             "value_probes_resident": world * ne * nres * nb / elapsed_resident,
             "value_pcie_inclusive_this_rank": ne * nres * nb / elapsed_pcie,
             "probe_generation_ms_per_batch": gen_ms,
+            "f32_preconditioner": f32_line,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using swk::cplx;
@@ -78,6 +79,11 @@ struct KrylovWS {
   int m = 0, n = 0, nbp = 0;
   cplx* V = nullptr;  // m vectors: vtilde_1 .. vtilde_m (vtilde_0 is the residual itself)
   cplx* Z = nullptr;  // m vectors
+  // single-precision preconditioner on the lattice level: its m directions stay complex64 (the widening
+  // is exact, so A z and x += Z y see the same numbers) and v32 is the complex64 copy of the Krylov
+  // vector it is applied to next, written by the kernel that produced that vector
+  cplxf* Z32 = nullptr;
+  cplxf* v32 = nullptr;
   cplx* xacc = nullptr;
   cplx* rres = nullptr;
   swk::FgScalars sc{};
@@ -159,6 +165,8 @@ struct sw_engine {
   int mfma_tiles = 4;
   int f32_tiles = 0;          // tiles of 16 probes per wave in k_bsr_mfma_f32 (0: automatic)
   int f32_stages = 4, f32_dense_stages = 8;
+  int f32_splitk = 1;         // split-K block-row kernel: 0 off, 1 dense coarsest inverse, 2 every small operator
+  bool f32_pairs = true;      // two probes per lane in the HBM-bound complex64 kernels (A/B switch)
   int mfma_small_tiles = 2;   // tiles per wave for operators too small to fill the chip (0: off)
   // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
@@ -538,10 +546,12 @@ static int stencil_spw(sw_engine* h, int tile_w) {
   return spw;
 }
 
-// Y = A X (mode 0), Y = B - A X (mode 1) or Y = X + w (B - A X) (mode 2) at a level
-static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* B, cplx* Y,
-                    int nbp, cplx w = cplx{0.0, 0.0}) {
-  if (lv.stencil) {
+// the Wilson stencil of the lattice level; CI = complex64: X is a direction stored by the
+// single-precision preconditioner (mode 0 only), widened on load
+template <class CI>
+static int launch_stencil(sw_engine* h, Level& lv, int mode, const CI* X, const cplx* B, cplx* Y,
+                          int nbp, cplx w) {
+  {
     swk::StencilArgs a;
     a.L = lv.L;
     a.Vh = lv.L * lv.L / 2;
@@ -563,13 +573,15 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     const int nchunks = nbp / 64;
     LaunchScope ls(h, mode == 0 ? T_STENCIL : (mode == 1 ? T_STENCIL_RES : T_STENCIL_SM));
 #define ST_LAUNCH(MD, SP)                                                                       \
-  hipLaunchKernelGGL((swk::k_stencil<MD, SP>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, \
+  hipLaunchKernelGGL((swk::k_stencil<MD, SP, CI>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, \
                      X, B, Y, a, bpc)
-#define ST_MODE(SP)                    \
-  do {                                 \
-    if (mode == 0) ST_LAUNCH(0, SP);   \
-    else if (mode == 1) ST_LAUNCH(1, SP); \
-    else ST_LAUNCH(2, SP);             \
+#define ST_MODE(SP)                                                  \
+  do {                                                               \
+    if (mode == 0) ST_LAUNCH(0, SP);                                 \
+    else if constexpr (std::is_same<CI, cplx>::value) {              \
+      if (mode == 1) ST_LAUNCH(1, SP);                               \
+      else ST_LAUNCH(2, SP);                                         \
+    } else return sw_fail(h, "internal: complex64 stencil input supports Y = A X only"); \
   } while (0)
     if (spw == 8) ST_MODE(8);
     else if (spw == 4) ST_MODE(4);
@@ -580,6 +592,12 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
     KLAUNCH_CHECK();
     return 0;
   }
+}
+
+// Y = A X (mode 0), Y = B - A X (mode 1) or Y = X + w (B - A X) (mode 2) at a level
+static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* B, cplx* Y,
+                    int nbp, cplx w = cplx{0.0, 0.0}) {
+  if (lv.stencil) return launch_stencil<cplx>(h, lv, mode, X, B, Y, nbp, w);
   return launch_ell(h, lv.A, mode == 2 ? 3 : mode, X, B, Y, nbp, T_MVM, w);
 }
 
@@ -629,8 +647,10 @@ static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n,
 }
 
 // Wout = Win + sign * sum_k coef[k] V_k ; optional nrm[col].x = ||Wout||^2
-static int multiaxpy(sw_engine* h, const PtrList& V, int K, const cplx* coef, double sign,
-                     const cplx* Win, cplx* Wout, int n, int nbp, cplx* nrm_out) {
+template <class CV>
+static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx* coef, double sign,
+                     const cplx* Win, cplx* Wout, int n, int nbp, cplx* nrm_out,
+                     cplxf* w32 = nullptr) {
   if (K < 1 || K > SW_MAXM + 2) return sw_fail(h, "multiaxpy: K=%d out of range", K);
   int P, rpb;
   row_blocking(n, nbp, nrm_out != nullptr, &P, &rpb);
@@ -641,11 +661,11 @@ static int multiaxpy(sw_engine* h, const PtrList& V, int K, const cplx* coef, do
 #define MA_CASE(KT)                                                                              \
   do {                                                                                           \
     if (nrm_out)                                                                                 \
-      hipLaunchKernelGGL((swk::k_multiaxpy<KT, true>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, \
-                         coef, sign, Win, Wout, n, nbp, rpb, h->partial);                        \
+      hipLaunchKernelGGL((swk::k_multiaxpy<KT, true, CV>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, \
+                         coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32);                   \
     else                                                                                         \
-      hipLaunchKernelGGL((swk::k_multiaxpy<KT, false>), grid, dim3(SW_BLOCK), 0, h->stream, V,   \
-                         K, coef, sign, Win, Wout, n, nbp, rpb, h->partial);                     \
+      hipLaunchKernelGGL((swk::k_multiaxpy<KT, false, CV>), grid, dim3(SW_BLOCK), 0, h->stream, V, \
+                         K, coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32);                \
   } while (0)
     if (K <= 2) MA_CASE(2);
     else if (K <= 4) MA_CASE(4);
@@ -706,6 +726,8 @@ static int ensure_level_ws(sw_engine* h, Level& lv, int nbp) {
 static int free_krylov(sw_engine* h, KrylovWS& w) {
   SWCHK(dev_free(h, w.V)); w.V = nullptr;
   SWCHK(dev_free(h, w.Z)); w.Z = nullptr;
+  SWCHK(dev_free(h, w.Z32)); w.Z32 = nullptr;
+  SWCHK(dev_free(h, w.v32)); w.v32 = nullptr;
   SWCHK(dev_free(h, w.xacc)); w.xacc = nullptr;
   SWCHK(dev_free(h, w.rres)); w.rres = nullptr;
   SWCHK(dev_free(h, w.sc.H)); w.sc.H = nullptr;
@@ -1128,8 +1150,8 @@ static int ensure_level_ws32(sw_engine* h, Level& lv, int nbp) {
   SWCHK(dev_realloc(h, &lv.x32, cnt));
   SWCHK(dev_realloc(h, &lv.r32, cnt));
   SWCHK(dev_realloc(h, &lv.t32, cnt));
-  SWCHK(dev_realloc(h, &lv.i32, cnt));
-  SWCHK(dev_realloc(h, &lv.o32, cnt));
+  SWCHK(dev_free(h, lv.i32)); lv.i32 = nullptr;   // boundary pair: made on demand for this width
+  SWCHK(dev_free(h, lv.o32)); lv.o32 = nullptr;
   lv.ws32_nbp = nbp;
   return 0;
 }
@@ -1150,6 +1172,28 @@ static int launch_bsr32(sw_engine* h, const EllOp& op, int mode, const cplxf* X,
                                                     : cat);
   LaunchScope ls(h, cls);
   if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
+  if ((h->f32_splitk == 1 && cat == T_COARSEST) ||
+      (h->f32_splitk == 2 && (long long)RT * (nbp / 64) < 4096 && op.bsr_KS >= 16)) {
+    // few (tile, chunk) pairs: four waves per pair, each a quarter of the k-steps
+    const int NTs = (h->f32_tiles == 1) ? 1 : 2;
+    const dim3 gsk(RT * (nbp / (16 * NTs)));
+#define SKF_LAUNCH(MD, NTT)                                                                       \
+  hipLaunchKernelGGL((swk::k_bsr_mfma_f32_sk<MD, NTT>), gsk, dim3(SW_BLOCK), 0, h->stream,         \
+                     (const cplxf*)op.bsr_vals32, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, B, Y, \
+                     nbp, w, (const int*)op.bsr_tmap)
+#define SKF_MODE(NTT)                      \
+  do {                                     \
+    if (mode == 0) SKF_LAUNCH(0, NTT);     \
+    else if (mode == 1) SKF_LAUNCH(1, NTT); \
+    else SKF_LAUNCH(3, NTT);               \
+  } while (0)
+    if (NTs == 1) SKF_MODE(1);
+    else SKF_MODE(2);
+#undef SKF_MODE
+#undef SKF_LAUNCH
+    KLAUNCH_CHECK();
+    return 0;
+  }
   const dim3 grid(RBn * NCn);
   const int stg = (cat == T_COARSEST) ? h->f32_dense_stages : h->f32_stages;
 #define BSRF_LAUNCH(MD, NTT, SG)                                                                  \
@@ -1217,50 +1261,64 @@ static int launch_ell32(sw_engine* h, const EllOp& op, int mode, const cplxf* X,
   return 0;
 }
 
-// even-odd post-smoothing of the stencil level in complex64 (eo_smooth's twin)
-static int eo_smooth32(sw_engine* h, Level& lv, const cplxf* Bin, cplxf* start, cplxf* other, cplxf* Xout,
-                       int nbp) {
-  swk::StencilArgsT<cplxf> a;
+// even-odd post-smoothing of the stencil level in complex64 (eo_smooth's twin).  C = cplxf2: two probes
+// per lane (16-B accesses, rows of nbp / 2 elements), used whenever nbp is a multiple of 128
+template <class C>
+static int eo_smooth32_t(sw_engine* h, Level& lv, const cplxf* Bin_, cplxf* start_, cplxf* other_,
+                         cplxf* Xout_, int nbp) {
+  const int per = (int)(sizeof(C) / sizeof(cplxf));   // probes per lane
+  const C* Bin = (const C*)Bin_;
+  C* start = (C*)start_;
+  C* other = (C*)other_;
+  C* Xout = (C*)Xout_;
+  swk::StencilArgsT<C> a;
   a.L = lv.L;
   a.Vh = lv.L * lv.L / 2;
   a.diag = (float)(4.0 + lv.mass);
   a.U1 = lv.U1f;
   a.U2 = lv.U2f;
-  a.nbp = nbp;
+  a.nbp = nbp / per;
   a.nt_store = 0;
   a.tile_w = lv.L;
-  // five lattice rows (1 KiB per site and 64-probe chunk, half the sites) must fit an XCD's L2
-  if (lv.L > 512) a.tile_w = (lv.L % 512 == 0) ? 512 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  // five lattice rows (1 KiB per site and 64-lane chunk, half the sites) must fit an XCD's L2
+  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
   if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
   a.w = cplxf{0.f, 0.f};
   const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
+  const dim3 grid(bpc * (a.nbp / 64));
   const float di = (float)(1.0 / (4.0 + lv.mass));
-  cplxf* bp = lv.r32;
+  C* bp = (C*)lv.r32;
   {
     LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<0, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0f,
+    hipLaunchKernelGGL((swk::k_eo_hop<0, C>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0f,
                        di, bpc);
     KLAUNCH_CHECK();
   }
-  cplxf* cur = start;
-  cplxf* nxt = other;
+  C* cur = start;
+  C* nxt = other;
   for (size_t k = 0; k < lv.w_eo.size(); ++k) {
     a.w = cplxf{(float)lv.w_eo[k].real(), (float)lv.w_eo[k].imag()};
     LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_schur_step<cplxf>), grid, dim3(SW_BLOCK), 0, h->stream, (const cplxf*)cur,
-                       (const cplxf*)bp, nxt, a, bpc);
+    hipLaunchKernelGGL((swk::k_schur_step<C>), grid, dim3(SW_BLOCK), 0, h->stream, (const C*)cur,
+                       (const C*)bp, nxt, a, bpc);
     KLAUNCH_CHECK();
     std::swap(cur, nxt);
   }
   if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
   {
     LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<1, cplxf>), grid, dim3(SW_BLOCK), 0, h->stream, Bin,
-                       (const cplxf*)Xout, Xout, a, di, di, bpc);
+    hipLaunchKernelGGL((swk::k_eo_hop<1, C>), grid, dim3(SW_BLOCK), 0, h->stream, Bin,
+                       (const C*)Xout, Xout, a, di, di, bpc);
     KLAUNCH_CHECK();
   }
   return 0;
+}
+
+static int eo_smooth32(sw_engine* h, Level& lv, const cplxf* Bin, cplxf* start, cplxf* other, cplxf* Xout,
+                       int nbp) {
+  if (nbp % 128 == 0 && h->f32_pairs)
+    return eo_smooth32_t<swk::cplxf2>(h, lv, Bin, start, other, Xout, nbp);
+  return eo_smooth32_t<cplxf>(h, lv, Bin, start, other, Xout, nbp);
 }
 
 static int vcycle32(sw_engine* h, Hier& H, int l, const cplxf* Bin, cplxf* Xout, int nbp) {
@@ -1271,14 +1329,25 @@ static int vcycle32(sw_engine* h, Hier& H, int l, const cplxf* Bin, cplxf* Xout,
   }
   Level& lv = H.lv[l];
   Level& lc = H.lv[l + 1];
-  if (!lv.rich || lv.gm_m > 0 || !lv.w_pre.empty() || lv.kcycle > 0)
-    return sw_fail(h, "precond_f32 supports fixed-polynomial post-smoothing cycles without K-cycles only "
+  if (!lv.rich || lv.gm_m > 0 || !lv.w_pre.empty())
+    return sw_fail(h, "precond_f32 supports fixed-polynomial post-smoothing cycles only "
                       "(level %d is configured otherwise)", l);
   SWCHK(ensure_level_ws32(h, lv, nbp));
   SWCHK(ensure_level_ws32(h, lc, nbp));
   if (!lv.P.set || !lv.R.set) return sw_fail(h, "transfer operators of level %d not set", l);
   SWCHK(launch_ell32(h, lv.R, 0, Bin, nullptr, lc.b32, nbp, T_R));
-  SWCHK(vcycle32(h, H, l + 1, lc.b32, lc.x32, nbp));
+  if (lv.kcycle > 0 && l + 1 < last) {
+    // K-cycle: the few-step inner FGMRES of the coarse system stays fp64 (its Hessenberg solve and
+    // orthogonalisation are precision-sensitive and small); its preconditioner is complex64 again
+    const size_t cc = (size_t)lc.n * nbp;
+    SWCHK(ensure_level_ws(h, lc, nbp));
+    SWCHK(cast_vec(h, (const cplxf*)lc.b32, lc.b, cc, T_AXPY));
+    SWCHK(ensure_krylov(h, lc.kws, lv.kcycle, lc.n, nbp, false));
+    SWCHK(fgmres(h, H, l + 1, lc.b, lc.x, 0.0, lv.kcycle, lv.kcycle, false, lc.kws, nbp, nullptr, true));
+    SWCHK(cast_vec(h, (const cplx*)lc.x, lc.x32, cc, T_AXPY));
+  } else {
+    SWCHK(vcycle32(h, H, l + 1, lc.b32, lc.x32, nbp));
+  }
   const cplxf z{0.f, 0.f};
   if (!lv.stencil && !lv.w_eo.empty() && lv.eo_op[0].set) {
     const bool odd_steps = (lv.w_eo.size() & 1) != 0;
@@ -1321,7 +1390,7 @@ static int vcycle32(sw_engine* h, Hier& H, int l, const cplxf* Bin, cplxf* Xout,
 static bool f32_capable(const Hier& H, int level) {
   for (int l = level; l < H.nlevels - 1; ++l) {
     const Level& lv = H.lv[l];
-    if (!lv.rich || lv.gm_m > 0 || !lv.w_pre.empty() || lv.kcycle > 0) return false;
+    if (!lv.rich || lv.gm_m > 0 || !lv.w_pre.empty()) return false;
     if (lv.stencil && lv.w_eo.empty()) return false;
   }
   return level < H.nlevels - 1;
@@ -1333,6 +1402,10 @@ static int vcycle_f32_boundary(sw_engine* h, Hier& H, int l, const cplx* Bin, cp
   Level& lv = H.lv[l];
   SWCHK(ensure_level_ws32(h, lv, nbp));
   const size_t cnt = (size_t)lv.n * nbp;
+  if (!lv.i32) {
+    SWCHK(dev_realloc(h, &lv.i32, cnt));
+    SWCHK(dev_realloc(h, &lv.o32, cnt));
+  }
   SWCHK(cast_vec(h, Bin, lv.i32, cnt, T_AXPY));
   SWCHK(vcycle32(h, H, l, lv.i32, lv.o32, nbp));
   return cast_vec(h, (const cplxf*)lv.o32, Xout, cnt, T_AXPY);
@@ -1358,6 +1431,18 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
   bool converged = false;
   SWCHK(zero_vec(h, X, n, nbp));
   const cplx* Rcur = B;
+  // single-precision preconditioner: on the lattice level its directions are kept complex64 and its
+  // input copy is written by the producer of each Krylov vector; elsewhere cast at the boundary
+  const bool pf32 = precond && h->precond_f32 && f32_capable(H, level);
+  const bool z32 = pf32 && outer && lv.stencil;
+  if (z32) {
+    SWCHK(ensure_f32(h, H));
+    SWCHK(ensure_level_ws32(h, lv, nbp));
+    if (!ws.Z32) {
+      SWCHK(dev_realloc(h, &ws.Z32, vec * m));
+      SWCHK(dev_realloc(h, &ws.v32, vec));
+    }
+  }
   while (done < maxiter && !converged) {
     // beta = ||r||
     {
@@ -1372,16 +1457,23 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     // the basis is kept unnormalised (k_fg_hess): vtilde_0 is the residual where it lies,
     // vtilde_{j+1} the orthogonalised A M vtilde_j -- no normalisation passes over the vectors
     auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
+    if (z32) SWCHK(cast_vec(h, Rcur, ws.v32, vec, T_AXPY));
     int j = 0;
     const int jmax = std::min(m, maxiter - done);
     for (; j < jmax; ++j) {
       const cplx* vj = vt(j);
       cplx* zj = ws.Z + vec * j;
       cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
-      if (precond && outer && h->precond_f32 && f32_capable(H, level)) SWCHK(vcycle_f32_boundary(h, H, level, vj, zj, nbp));
-      else if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
-      else SWCHK(copy_vec(h, zj, vj, n, nbp));
-      SWCHK(apply_op(h, lv, 0, zj, nullptr, w, nbp));
+      cplxf* zj32 = z32 ? ws.Z32 + vec * j : nullptr;
+      if (z32) {
+        SWCHK(vcycle32(h, H, level, ws.v32, zj32, nbp));
+        SWCHK(launch_stencil<cplxf>(h, lv, 0, zj32, nullptr, w, nbp, cplx{0.0, 0.0}));
+      } else {
+        if (pf32) SWCHK(vcycle_f32_boundary(h, H, level, vj, zj, nbp));
+        else if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
+        else SWCHK(copy_vec(h, zj, vj, n, nbp));
+        SWCHK(apply_op(h, lv, 0, zj, nullptr, w, nbp));
+      }
       PtrList pv;
       for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
       // pass 1: raw dots d1 = Vt^H w, coefficients c = svec^2 d1 ; w -= Vt c
@@ -1390,9 +1482,9 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, nullptr));
         // pass 2 (re-orthogonalisation): d2 = Vt^H w ; w -= Vt (svec^2 d2) ; ||w||^2
         SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2, ws.sc.svec, ws.c1));
-        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
       } else {
-        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
         HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
       }
       if (outer) HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
@@ -1422,9 +1514,15 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       hipLaunchKernelGGL(swk::k_fg_solve, dim3(tg), dim3(tb), 0, h->stream, ws.sc, k);
       KLAUNCH_CHECK();
     }
-    PtrList pz;
-    for (int q = 0; q < k; ++q) pz.p[q] = ws.Z + vec * q;
-    SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n, nbp, nullptr));
+    if (z32) {
+      swk::PtrListT<cplxf> pz;
+      for (int q = 0; q < k; ++q) pz.p[q] = ws.Z32 + vec * q;
+      SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n, nbp, nullptr));
+    } else {
+      PtrList pz;
+      for (int q = 0; q < k; ++q) pz.p[q] = ws.Z + vec * q;
+      SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n, nbp, nullptr));
+    }
     done += k;
     first = false;
     if (!outer) break;
@@ -2255,6 +2353,14 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     const int v = (int)value;
     if (v != 0 && v != 1 && v != 2 && v != 4) return sw_fail(h, "f32_tiles must be 0, 1, 2 or 4");
     h->f32_tiles = v;
+    return 0;
+  }
+  if (std::strcmp(name, "f32_splitk") == 0) {
+    h->f32_splitk = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "f32_pairs") == 0) {
+    h->f32_pairs = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "f32_stages") == 0) {

@@ -66,14 +66,58 @@ __device__ __forceinline__ void cfma(cplxf& acc, cplxf a, cplxf b) {
   acc.y = fmaf(a.y, b.x, acc.y);
 }
 __device__ __forceinline__ cplxf cmuli(cplxf a) { return cmake(-a.y, a.x); }
+// two complex64 probes per lane: keeps the 16-B-per-lane (1 KiB per wave) accesses of the fp64 layout
+// in the HBM-bound complex64 kernels; a [n][nbp] complex64 array is read as [n][nbp/2] of these
+struct alignas(16) cplxf2 {
+  cplxf a, b;
+};
+__device__ __forceinline__ cplxf2 cadd(cplxf2 p, cplxf2 q) { return cplxf2{cadd(p.a, q.a), cadd(p.b, q.b)}; }
+__device__ __forceinline__ cplxf2 csub(cplxf2 p, cplxf2 q) { return cplxf2{csub(p.a, q.a), csub(p.b, q.b)}; }
+__device__ __forceinline__ cplxf2 cmuli(cplxf2 p) { return cplxf2{cmuli(p.a), cmuli(p.b)}; }
+// scalar (link / weight) times pair
+__device__ __forceinline__ cplxf2 cmul(cplxf u, cplxf2 p) { return cplxf2{cmul(u, p.a), cmul(u, p.b)}; }
+__device__ __forceinline__ cplxf2 cmulc(cplxf u, cplxf2 p) { return cplxf2{cmulc(u, p.a), cmulc(u, p.b)}; }
+__device__ __forceinline__ void cfma(cplxf2& acc, cplxf u, cplxf2 p) {
+  cfma(acc.a, u, p.a);
+  cfma(acc.b, u, p.b);
+}
 template <class C> struct real_of;
 template <> struct real_of<cplx> { typedef double type; };
 template <> struct real_of<cplxf> { typedef float type; };
+template <> struct real_of<cplxf2> { typedef float type; };
+// the scalar complex type that multiplies a vector element (gauge links, weights)
+template <class C> struct scalar_of { typedef C type; };
+template <> struct scalar_of<cplxf2> { typedef cplxf type; };
+// alpha u + beta v, real alpha and beta
+__device__ __forceinline__ cplx clin(double al, cplx u, double be, cplx v) {
+  return cmake(fma(al, u.x, be * v.x), fma(al, u.y, be * v.y));
+}
+__device__ __forceinline__ cplxf clin(float al, cplxf u, float be, cplxf v) {
+  return cmake(fmaf(al, u.x, be * v.x), fmaf(al, u.y, be * v.y));
+}
+__device__ __forceinline__ cplxf2 clin(float al, cplxf2 u, float be, cplxf2 v) {
+  return cplxf2{clin(al, u.a, be, v.a), clin(al, u.b, be, v.b)};
+}
+// q - d c + di acc  (residual of the Schur complement: b' - (D x - acc / D))
+__device__ __forceinline__ cplx cschur(cplx q, double d, cplx c, double di, cplx acc) {
+  return cmake(q.x - d * c.x + di * acc.x, q.y - d * c.y + di * acc.y);
+}
+__device__ __forceinline__ cplxf cschur(cplxf q, float d, cplxf c, float di, cplxf acc) {
+  return cmake(q.x - d * c.x + di * acc.x, q.y - d * c.y + di * acc.y);
+}
+__device__ __forceinline__ cplxf2 cschur(cplxf2 q, float d, cplxf2 c, float di, cplxf2 acc) {
+  return cplxf2{cschur(q.a, d, c.a, di, acc.a), cschur(q.b, d, c.b, di, acc.b)};
+}
+__device__ __forceinline__ cplx widen(cplx v) { return v; }
+__device__ __forceinline__ cplx widen(cplxf v) { return cmake((double)v.x, (double)v.y); }
 template <class C> __device__ __forceinline__ C czero() {
   C r;
   r.x = 0;
   r.y = 0;
   return r;
+}
+template <> __device__ __forceinline__ cplxf2 czero<cplxf2>() {
+  return cplxf2{cmake(0.f, 0.f), cmake(0.f, 0.f)};
 }
 
 // Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH, Workgroup dispatch); this
@@ -96,11 +140,11 @@ struct StencilArgsT {
   int L;          // lattice extent (even)
   int Vh;         // L*L/2
   typename real_of<C>::type diag;    // 4 + mass
-  const C* U1;    // [L*L] site index y*L+x
-  const C* U2;
-  int nbp;
+  const typename scalar_of<C>::type* U1;    // [L*L] site index y*L+x
+  const typename scalar_of<C>::type* U2;
+  int nbp;             // row length in elements of C
   int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
-  C w;                 // MODE 2 relaxation weight
+  typename scalar_of<C>::type w;   // MODE 2 relaxation weight
   int nt_store;        // non-temporal output stores
 };
 typedef StencilArgsT<cplx> StencilArgs;
@@ -112,8 +156,10 @@ __device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
   return ((size_t)par * Vh + sh) * 2;
 }
 
-template <int MODE, int SPW>
-__global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X,
+// CI: storage type of X (complex64 when X is a direction made by the single-precision
+// preconditioner; widened on load -- the arithmetic is fp64 either way)
+template <int MODE, int SPW, class CI = cplx>
+__global__ __launch_bounds__(SW_BLOCK) void k_stencil(const CI* __restrict__ X,
                                                       const cplx* __restrict__ B,
                                                       cplx* __restrict__ Y, StencilArgs a,
                                                       int blocks_per_chunk) {
@@ -138,14 +184,15 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
   const int x0 = tile * tw + (rem - y * tw);
   const int yp = (y + 1 == L) ? 0 : y + 1;
   const int ym = (y == 0) ? L - 1 : y - 1;
-  const cplx* Xc = X + col;
+  const CI* Xc = X + col;
+#define SW_LDX(ROW) widen(Xc[(ROW) * nbp])
   // one wave = SPW consecutive x-sites of one lattice row x 64 probes; the x-neighbours slide
   // through registers (left, centre, right), so a site costs 3 site-loads instead of 5
   const int xl = (x0 == 0) ? L - 1 : x0 - 1;
   size_t r_l = eo_row(xl, y, L, a.Vh);
   size_t r_c = eo_row(x0, y, L, a.Vh);
-  cplx l0 = Xc[r_l * nbp], l1 = Xc[(r_l + 1) * nbp];
-  cplx c0 = Xc[r_c * nbp], c1 = Xc[(r_c + 1) * nbp];
+  cplx l0 = SW_LDX(r_l), l1 = SW_LDX(r_l + 1);
+  cplx c0 = SW_LDX(r_c), c1 = SW_LDX(r_c + 1);
   cplx u1m = a.U1[y * L + xl];
 #pragma unroll
   for (int s = 0; s < SPW; ++s) {
@@ -154,9 +201,9 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
     const size_t r_xp = eo_row(xp, y, L, a.Vh);
     const size_t r_yp = eo_row(x, yp, L, a.Vh);
     const size_t r_ym = eo_row(x, ym, L, a.Vh);
-    const cplx a0 = Xc[r_xp * nbp], a1 = Xc[(r_xp + 1) * nbp];
-    const cplx d0 = Xc[r_yp * nbp], d1 = Xc[(r_yp + 1) * nbp];
-    const cplx e0 = Xc[r_ym * nbp], e1 = Xc[(r_ym + 1) * nbp];
+    const cplx a0 = SW_LDX(r_xp), a1 = SW_LDX(r_xp + 1);
+    const cplx d0 = SW_LDX(r_yp), d1 = SW_LDX(r_yp + 1);
+    const cplx e0 = SW_LDX(r_ym), e1 = SW_LDX(r_ym + 1);
     const int n = y * L + x;
     const cplx u1 = a.U1[n];
     const cplx u2 = a.U2[n];
@@ -202,6 +249,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const cplx* __restrict__ X
     r_c = r_xp;
     u1m = u1;
   }
+#undef SW_LDX
 }
 
 // ------------------------------------------------------------------------------------------
@@ -412,7 +460,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step_lds(const cplx* __re
 // contribution of one hop to a 2-spinor: dir 0:+x (1-s1) u psi, 1:-x (1+s1) conj(u) psi,
 // 2:+y (1-s2) u psi, 3:-y (1+s2) conj(u) psi   (u = the link the hop runs along)
 template <int DIR, class C>
-__device__ __forceinline__ void hop_acc(SiteT<C>& acc, C u, SiteT<C> psi) {
+__device__ __forceinline__ void hop_acc(SiteT<C>& acc, typename scalar_of<C>::type u, SiteT<C> psi) {
   if (DIR == 0) {
     const C t = cmul(u, csub(psi.s0, psi.s1));
     acc.s0 = cadd(acc.s0, t);
@@ -477,8 +525,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const C* __restrict__ Uv,
   hop_acc<3>(acc, a.U2[ym * L + x], ld_site(S, x, ym, L, Vh, nbp));
   const size_t r = eo_row(x, y, L, Vh);
   const C u0 = Uv[r * nbp + col], u1 = Uv[(r + 1) * nbp + col];
-  out[r * nbp + col] = cmake(rfma(alpha, u0.x, beta * acc.s0.x), rfma(alpha, u0.y, beta * acc.s0.y));
-  out[(r + 1) * nbp + col] = cmake(rfma(alpha, u1.x, beta * acc.s1.x), rfma(alpha, u1.y, beta * acc.s1.y));
+  out[r * nbp + col] = clin(alpha, u0, beta, acc.s0);
+  out[(r + 1) * nbp + col] = clin(alpha, u1, beta, acc.s1);
 }
 
 // Y_e = X_e + w (Bp_e - S X_e),  S = D - H_eo H_oe / D : both hops in one kernel (even sites only)
@@ -507,8 +555,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
   const Site2 e02 = ld_site(Xc, x, ypp, L, Vh, nbp), e0m2 = ld_site(Xc, x, ymm, L, Vh, nbp);
   const Site2 ePP = ld_site(Xc, xp, yp, L, Vh, nbp), ePM = ld_site(Xc, xp, ym, L, Vh, nbp);
   const Site2 eMP = ld_site(Xc, xm, yp, L, Vh, nbp), eMM = ld_site(Xc, xm, ym, L, Vh, nbp);
-  const C* U1 = a.U1;
-  const C* U2 = a.U2;
+  const typename scalar_of<C>::type* U1 = a.U1;
+  const typename scalar_of<C>::type* U2 = a.U2;
 #define SW_U1(xx, yy) U1[(yy) * L + (xx)]
 #define SW_U2(xx, yy) U2[(yy) * L + (xx)]
   Site2 z;
@@ -543,8 +591,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
   const C c0 = Xc[r * nbp], c1 = Xc[(r + 1) * nbp];
   const C q0 = Bp[r * nbp + col], q1 = Bp[(r + 1) * nbp + col];
   // residual of S: b' - (D x - acc / D)
-  const C r0 = cmake(q0.x - d * c0.x + di * acc.s0.x, q0.y - d * c0.y + di * acc.s0.y);
-  const C r1 = cmake(q1.x - d * c1.x + di * acc.s1.x, q1.y - d * c1.y + di * acc.s1.y);
+  const C r0 = cschur(q0, d, c0, di, acc.s0);
+  const C r1 = cschur(q1, d, c1, di, acc.s1);
   C o0 = c0, o1 = c1;
   cfma(o0, a.w, r0);
   cfma(o1, a.w, r1);
@@ -931,6 +979,97 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma_f32(const cplxf* __restri
   }
 }
 
+// Split-K twin for operators with few (tile, chunk) pairs and long rows (the dense coarsest inverse:
+// 64 row tiles x 256 k-steps): the four waves of a workgroup share one (row tile, probe chunk), wave q
+// takes the k-steps q, q+4, ..., the partial accumulators meet in LDS and wave 0 runs the epilogue.
+template <int MODE, int NT>
+__global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma_f32_sk(const cplxf* __restrict__ Ap,
+                                                              const int* __restrict__ kcol, int KS,
+                                                              int RT, const cplxf* __restrict__ X,
+                                                              const cplxf* __restrict__ B,
+                                                              cplxf* __restrict__ Y, int nbp, cplxf w,
+                                                              const int* __restrict__ tmap) {
+  __shared__ float red[3][NT * 8][64];
+  const int lane = threadIdx.x & 63;
+  const int q = threadIdx.x >> 6;
+  const int rt = blockIdx.x % RT;
+  const int cy = blockIdx.x / RT;
+  const int c0 = cy * (16 * NT);
+  const cplxf* a = Ap + (size_t)rt * KS * 64 + lane;
+  const int* kc = kcol + (size_t)rt * KS;
+  const cplxf* b = X + (size_t)(lane >> 4) * nbp + c0 + (lane & 15);
+  sw_float4 re[NT], im[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    re[t] = sw_float4{0.f, 0.f, 0.f, 0.f};
+    im[t] = re[t];
+  }
+  constexpr int STG = 4;
+  cplxf mm[STG];
+  cplxf xx[STG][NT];
+#define SW_SKF_LOAD(S_, KSI)                                                  \
+  {                                                                           \
+    const int ks_ = ((KSI) < KS) ? (KSI) : q;                                 \
+    mm[S_] = a[(size_t)ks_ * 64];                                             \
+    const cplxf* bk_ = b + (size_t)kc[ks_] * nbp;                             \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) xx[S_][t] = bk_[t * 16];   \
+  }
+#pragma unroll
+  for (int s = 0; s < STG; ++s) SW_SKF_LOAD(s, q + 4 * s);
+  for (int ks = q; ks < KS; ks += 4 * STG) {
+#pragma unroll
+    for (int s = 0; s < STG; ++s) {
+      if (ks + 4 * s < KS) {
+        __builtin_amdgcn_sched_barrier(0);
+        const float nay = -mm[s].y;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mm[s].x, xx[s][t].x, re[t], 0, 0, 0);
+          im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mm[s].x, xx[s][t].y, im[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(nay, xx[s][t].y, re[t], 0, 0, 0);
+          im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mm[s].y, xx[s][t].x, im[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SW_SKF_LOAD(s, ks + 4 * s + 4 * STG);
+      }
+    }
+  }
+#undef SW_SKF_LOAD
+  if (q > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[q - 1][t * 8 + r][lane] = re[t][r];
+        red[q - 1][t * 8 + 4 + r][lane] = im[t][r];
+      }
+  }
+  __syncthreads();
+  if (q != 0) return;
+  const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t row = (size_t)ot * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const size_t off = row * nbp + c0 + t * 16 + (lane & 15);
+      cplxf y = cmake(re[t][r] + red[0][t * 8 + r][lane] + red[1][t * 8 + r][lane] + red[2][t * 8 + r][lane],
+                      im[t][r] + red[0][t * 8 + 4 + r][lane] + red[1][t * 8 + 4 + r][lane] +
+                          red[2][t * 8 + 4 + r][lane]);
+      if (MODE == 1) y = csub(B[off], y);
+      if (MODE == 3) {
+        cplxf o = X[off];
+        cfma(o, w, csub(B[off], y));
+        y = o;
+      }
+      Y[off] = y;
+    }
+  }
+}
+
 // precision boundary of the single-precision preconditioner: dst = (CO) src, element-wise
 template <class CI, class CO>
 __global__ __launch_bounds__(SW_BLOCK) void k_cast(const CI* __restrict__ src, CO* __restrict__ dst,
@@ -1183,9 +1322,11 @@ __global__ __launch_bounds__(SW_MT_BLOCK) void k_mt_generate(const uint32_t* __r
 // ------------------------------------------------------------------------------------------
 #define SW_MAXK 34   // restart cap 32, + w itself + 1
 
-struct PtrList {
-  const cplx* p[SW_MAXK];
+template <class C>
+struct PtrListT {
+  const C* p[SW_MAXK];
 };
+typedef PtrListT<cplx> PtrList;
 
 // partial[(blockIdx.x*K + k)*nbp + col] = sum over this block's rows of conj(V_k[r]) * W[r]
 template <int KT>
@@ -1279,13 +1420,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_reduce_partials(const cplx* __rest
 
 // Wout[r] = Win[r] + sign * sum_k coef[k][col] * V_k[r]; optionally partial |Wout|^2 sums
 // (as the real part of a cplx partial, layout as k_multidot with K = 1).
-template <int KT, bool NORM>
-__global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrList V, int K,
+// CV: storage type of the V vectors (complex64 for the preconditioned directions Z of the
+// single-precision preconditioner, widened on load); W32 (optional): complex64 copy of Wout, the
+// next input of that preconditioner.
+template <int KT, bool NORM, class CV = cplx>
+__global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrListT<CV> V, int K,
                                                         const cplx* __restrict__ coef, double sign,
                                                         const cplx* __restrict__ Win,
                                                         cplx* __restrict__ Wout, int n, int nbp,
                                                         int rows_per_block,
-                                                        cplx* __restrict__ partial) {
+                                                        cplx* __restrict__ partial,
+                                                        cplxf* __restrict__ W32) {
   __shared__ double redn[3][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t col = (size_t)blockIdx.y * 64 + lane;
@@ -1307,8 +1452,12 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrList V, int K,
     cplx w = Win[off];
 #pragma unroll
     for (int k = 0; k < KT; ++k)
-      if (k < K) cfma(w, c[k], V.p[k][off]);
+      if (k < K) {
+        const CV v = V.p[k][off];
+        cfma(w, c[k], cmake((double)v.x, (double)v.y));
+      }
     Wout[off] = w;
+    if (W32) W32[off] = cmake((float)w.x, (float)w.y);
     if (NORM) nrm = fma(w.x, w.x, fma(w.y, w.y, nrm));
   }
   if (NORM) {

@@ -398,6 +398,16 @@ def eo_levels_of(cfg):
     return sorted(lv)
 
 
+def f32_capable(cfg):
+    """Can the engine run this solver configuration's cycle in complex64 (option precond_f32)?  The
+    complex64 path covers the fixed-polynomial cycles without pre-smoothing (K-cycles keep their small
+    inner FGMRES in fp64), with the lattice level smoothed even-odd (the engine's own check is
+    sw_engine.hip: f32_capable)."""
+    if cfg.get("smoother", "richardson") != "richardson" or 0 not in eo_levels_of(cfg):
+        return False
+    return all(int(c[0]) == 0 for c in cfg["cycle"])
+
+
 def upload_coarse_eo(engines, hid, level, A_l, Lc, degree):
     """Build the four even-odd operators of block level `level` on the host, hand them to the engines
     and select `degree` Schur steps as its post-smoother.  Returns (weights, ops)."""

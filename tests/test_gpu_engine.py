@@ -940,16 +940,19 @@ def test_even_odd_smoother_on_block_levels_matches_model(p128):
         p.mg.upload_solver_hierarchy(None)
 
 
-def test_single_precision_preconditioner_keeps_fp64_results(p128):
+@pytest.mark.parametrize("kcycle", [0, 2])
+def test_single_precision_preconditioner_keeps_fp64_results(p128, kcycle):
     """Option precond_f32 (cfg key precond_precision = "f32"): the multigrid cycle inside the fp64
     flexible GMRES runs in complex64 (k_bsr_mfma_f32, k_schur_step<float2>, k_ell<.., float2>).
     The cycle itself equals the fp64 cycle to single-precision round-off; the converged solves are fp64:
     per-probe estimates against the sparse-LU oracle at the north-star tolerance 1e-10, with the
-    iteration count of the fp64 preconditioner (+-2)."""
+    iteration count of the fp64 preconditioner (+-2).  With a K-cycle the small inner FGMRES stays fp64
+    and only its preconditioner is complex64."""
     from deflatedmlmc_schwinger_amd import hierarchy
     p = p128
     base = dict(hierarchy.DEFAULT_SOLVER_CFG, coarsening=[(4, 8), (2, 8), (2, 8)],
-                cycle=[(0, 4, 0), (0, 3, 0), (0, 5, 0)], eo_levels=[0, 1, 2])
+                cycle=[(0, 4, 0), (0, 3, kcycle), (0, 5, 0)], eo_levels=[0, 1, 2])
+    assert hierarchy.f32_capable(base)
     n = p.A.shape[0]
     np.random.seed(4242)
     probes = utils.draw_probes(70, n)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # f32 preconditioner: parity test + A/B bench (one GPU call)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python3 -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "single_precision or even_odd" > gpurun_out/f32_test.log 2>&1
+timeout -k 10 500 python3 -m pytest tests/test_gpu_engine.py -x -q -m gpu -k "${F32_TESTS:-single_precision or even_odd}" > gpurun_out/f32_test.log 2>&1
 echo "pytest rc=$?"; tail -15 gpurun_out/f32_test.log
-for o in "" "precond_f32=1" "precond_f32=1,f32_tiles=2" "precond_f32=1,f32_stages=8" "precond_f32=1,f32_stages=2"; do
+for o in ${F32_OPTS:-"" "precond_f32=1"}; do
   timeout -k 10 200 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-large-stencil --engine-opts "$o" > gpurun_out/_b.json 2> gpurun_out/_b.err || { echo "opts=$o FAILED"; tail -5 gpurun_out/_b.err; continue; }
   python3 - "$o" <<'PY'
 import json, sys

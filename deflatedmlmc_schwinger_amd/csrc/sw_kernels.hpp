@@ -671,6 +671,12 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 // MODE 0: Y = A X   MODE 1: Y = B - A X   MODE 3: Y = X + w (B - A X)
 // ------------------------------------------------------------------------------------------
 typedef double sw_double4 __attribute__((ext_vector_type(4)));
+// waves per SIMD the register allocator must leave room for (NT = 4 with 4 stages lands on 128 + 64
+// registers = 2 waves without it)
+#ifndef SW_BSR_WAVES_NT4
+#define SW_BSR_WAVES_NT4 3
+#endif
+#define SW_BSR_MIN_WAVES(NT_, STG_) (((NT_) == 4 && (STG_) <= 4) ? SW_BSR_WAVES_NT4 : 1)
 
 // epilogue of the block-row kernels: re/im exchange between neighbour lanes, mode arithmetic, store
 template <int MODE, int NT, bool NTIO>
@@ -708,7 +714,7 @@ __device__ __forceinline__ void bsr_store(const sw_double4 (&re)[NT], const sw_d
 }
 
 template <int MODE, int NT, bool NTIO = false, int STG = 2>
-__global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ Ap,
+__global__ __launch_bounds__(SW_BLOCK, SW_BSR_MIN_WAVES(NT, STG)) void k_bsr_mfma(const cplx* __restrict__ Ap,
                                                        const int* __restrict__ kcol, int KS,
                                                        int RT, const double* __restrict__ Xr,
                                                        const double* __restrict__ Br,
@@ -726,6 +732,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma(const cplx* __restrict__ 
   //   0: chunk-major, the row blocks of one chunk dealt to the XCDs in contiguous bands
   //   1: XCD band of row blocks, the NC chunks of a row block adjacent in time (A tile read once)
   //   2: as 1, in sub-bands of `msub` row blocks: chunk loop over a sub-band, then the next one
+  // (four row tiles x one chunk per workgroup; 2 x 2 and 1 x 4 -- chunk-mates sharing each A tile in
+  // L1 -- were measured identical: the A stream is not what the kernel waits for)
   const int RB = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
   const int NC = (gridDim.y > 1) ? gridDim.y : gridDim.x / RB;
   int bx, cy;

@@ -8,11 +8,13 @@ engine: no sparse factorisation, setup cost of a few batched solves, and it scal
 where SuperLU on the host is impractical.  Galerkin products and the per-aggregate QR stay on
 the host (SciPy / NumPy).
 """
+import sys
 import time
 
 import numpy as np
 import scipy.sparse as sp
 
+from . import engine as _engine
 from . import hierarchy as _hier
 
 
@@ -235,9 +237,16 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
     def finish():
         """coarsest inverse (host, as multigrid.py:342-344), cycle shapes, smoother polynomials."""
         with _timed("coarsest_inverse"):
+            done = False
             if cfg.get("setup_inverse", "device") == "device":
-                eng.setup_invert_coarsest(hid)                 # rocSOLVER LU on the GPU
-            else:
+                try:
+                    eng.setup_invert_coarsest(hid)             # rocSOLVER LU on the GPU
+                    done = True
+                except _engine.EngineError as err:
+                    # rocSOLVER / rocBLAS unavailable or refusing a handle: the same LU inverse on
+                    # the host (setup only, never the solve path)
+                    sys.stderr.write("setup_gpu: %s -- inverting the coarsest operator on the host\n" % err)
+            if not done:
                 eng.set_coarsest_inv(hid, _hier.dense_inverse(eng.level_dense(hid, nl - 1)))
             eng.hier_end(hid)
         with _timed("smoother_polynomials"):

@@ -132,8 +132,12 @@ static void test_bsr(std::mt19937& rng) {
     Csr A = random_csr(n, n, 12, rng, true);
     swp::BsrHost b;
     swp::bsr_pack(b, n, A.indptr.data(), A.indices.data(), A.data.data(), 0.0);
-    CHECK(b.KS > 0 && b.KS % 2 == 0, "bsr_pack KS %d", b.KS);
+    CHECK(b.KS > 0 && b.KS % 4 == 0, "bsr_pack KS %d", b.KS);
     if (b.KS == 0) continue;
+    // the diagonal block's four column groups are the last four k-steps of every row tile
+    for (int rt = 0; rt < n / 16; ++rt)
+      for (int d = 0; d < 4; ++d)
+        CHECK(b.kcol[(size_t)rt * b.KS + b.KS - 4 + d] == 16 * rt + 4 * d, "diagonal block not last (tile %d)", rt);
     std::vector<cd> x(n);
     for (auto& v : x) v = cd(u(rng), u(rng));
     const std::vector<cd> yref = csr_apply(A, x);

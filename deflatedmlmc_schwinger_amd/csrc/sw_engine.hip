@@ -73,6 +73,7 @@ struct EllOp {
   cplx* bsr_vals = nullptr;  // [n/16][KS][64] lane-packed
   int* bsr_tmap = nullptr;   // optional: row tile -> tile of the output vector (subset operators)
   int bsr_RT = 0;            // row tiles when != nrows / 16 (subset operators)
+  bool bsr_diag_last = false;   // the last four k-steps of every row tile are its own X rows (check_diag_last)
   // complex64 mirrors of the value arrays (same index arrays), made on demand for the
   // single-precision preconditioner (option precond_f32)
   cplxf* vals32 = nullptr;
@@ -164,6 +165,7 @@ struct sw_engine {
   int bsr_map = 1, bsr_sub = 8, dense_map = 0;   // block orderings of k_bsr_mfma (see the kernel)
   bool bsr_nt = true;     // non-temporal B loads / Y stores in k_bsr_mfma on level operators
   bool ell_order = true;   // visit prolongator row groups sorted by column (A/B switch)
+  bool bsr_xreg = true;    // smoother step of a block operator: own X rows from the operand registers (A/B switch)
   bool p_even = true;      // prolongate onto the even sites only ahead of an even-odd smoother (A/B switch)
   int bench_what = 0;      // what sw_bench_dirac times: 0 operator, 1 restrict, 2 prolong, 3 coarsest inverse
   int bench_mode = 0;      // operator mode sw_bench_dirac times (0: Y=AX, 1: residual, 2: smoother step)
@@ -395,6 +397,7 @@ static int build_ell(sw_engine* h, EllOp& op, int nrows, int ncols, const int64_
 
 // MFMA block-row form of a square CSR operator in natural order (level >= 1 operators and the
 // dense inverse).  Built only when at least `min_fill` of the packed 16x4 groups is non-zero.
+static void check_diag_last(EllOp& op, const int32_t* kcol, const int32_t* tmap);
 static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, const int32_t* indices,
                      const std::complex<double>* data, double min_fill) {
   swp::BsrHost b;
@@ -404,7 +407,25 @@ static int build_bsr(sw_engine* h, EllOp& op, int n, const int64_t* indptr, cons
   SWCHK(upload(h, &op.bsr_kcol, b.kcol.data(), b.kcol.size()));
   SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, b.vals.data(), b.vals.size()));
   op.bsr_KS = b.KS;
+  if (op.nrows == 0) op.nrows = n;
+  check_diag_last(op, b.kcol.data(), nullptr);
   return 0;
+}
+
+// Does every row tile end with its own diagonal block (k-steps KS-4 .. KS-1 = X rows 16 ot + 4 r)?
+// The packers arrange it (sw_pack.hpp, hierarchy.block_rows_from_matrix, setup_gpu.level_geometry);
+// the kernel's register shortcut is only taken where this check, on the index array itself, passes.
+static void check_diag_last(EllOp& op, const int32_t* kcol, const int32_t* tmap) {
+  op.bsr_diag_last = false;
+  const int KS = op.bsr_KS;
+  const int RT = op.bsr_RT > 0 ? op.bsr_RT : op.nrows / 16;
+  if (KS < 4 || KS % 4 || RT <= 0 || !kcol) return;
+  for (int rt = 0; rt < RT; ++rt) {
+    const int ot = tmap ? tmap[rt] : rt;
+    for (int r = 0; r < 4; ++r)
+      if (kcol[(size_t)rt * KS + KS - 4 + r] != 16 * ot + 4 * r) return;
+  }
+  op.bsr_diag_last = true;
 }
 
 static int free_op(sw_engine* h, EllOp& op) {
@@ -468,7 +489,8 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
 #define BSR_LAUNCH_S(MD, NTT, NTB, SG)                                                           \
   hipLaunchKernelGGL((swk::k_bsr_mfma<MD, NTT, NTB, SG>), grid, dim3(SW_BLOCK), 0, h->stream,   \
                      (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, Xr, Br,   \
-                     Yr, 2 * nbp, nbp, w, bmap, msub, (const int*)op.bsr_tmap)
+                     Yr, 2 * nbp, nbp, w, bmap, msub, (const int*)op.bsr_tmap,                  \
+                     (op.bsr_diag_last && h->bsr_xreg) ? 1 : 0)
 #define BSR_LAUNCH(MD, NTT)                                                                     \
   do {                                                                                          \
     const bool ntio_ = h->bsr_nt && cat != T_COARSEST;                                          \
@@ -2090,7 +2112,8 @@ int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* n
     if (nbr[i] < 0 || nbr[i] >= ncs) return sw_fail(h, "neighbour site out of range");
   for (int I = 0; I < ncs; ++I)
     for (int a = 1; a < 5; ++a)
-      if (nbr[I * 5 + a] <= nbr[I * 5 + a - 1]) return sw_fail(h, "neighbour lists must be strictly increasing");
+      for (int b = 0; b < a; ++b)
+        if (nbr[I * 5 + a] == nbr[I * 5 + b]) return sw_fail(h, "neighbour lists must hold five distinct sites");
   const int nbp = 256;
   cplx *E = nullptr, *X = nullptr, *Y = nullptr;
   SWCHK(dev_realloc(h, &E, (size_t)n_c * nbp));
@@ -2122,6 +2145,12 @@ int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* n
   }
   A.set = true;
   SWCHK(stream_sync(h));
+  {
+    // the k-step columns are 16 nbr + 4 g: the own-site-last property can be read off nbr
+    bool last = Lc > 1;
+    for (int I = 0; I < ncs && last; ++I) last = nbr[I * 5 + 4] == I;
+    A.bsr_diag_last = last;
+  }
   SWCHK(dev_free(h, dnbr));
   SWCHK(dev_free(h, E));
   SWCHK(dev_free(h, X));
@@ -2290,6 +2319,7 @@ int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int 
   SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, (const std::complex<double>*)vals,
                (size_t)RT * KS * 64));
   op.set = true;
+  check_diag_last(op, kcol, tmap);
   return 0;
 }
 
@@ -2379,6 +2409,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "bsr_nt") == 0) {
     h->bsr_nt = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "bsr_xreg") == 0) {
+    h->bsr_xreg = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "p_even") == 0) {

@@ -679,12 +679,14 @@ typedef double sw_double4 __attribute__((ext_vector_type(4)));
 #define SW_BSR_MIN_WAVES(NT_, STG_) (((NT_) == 4 && (STG_) <= 4) ? SW_BSR_WAVES_NT4 : 1)
 
 // epilogue of the block-row kernels: re/im exchange between neighbour lanes, mode arithmetic, store
+// xown (MODE 3, optional): the wave's own X values xown[r][t] = X''[16 ot + (lane>>4) + 4r][c0 + 16t + c],
+// left in the operand registers by the diagonal block's four k-steps when these come last
 template <int MODE, int NT, bool NTIO>
 __device__ __forceinline__ void bsr_store(const sw_double4 (&re)[NT], const sw_double4 (&im)[NT], int rt,
                                           int c0, int lane, const int* __restrict__ tmap,
                                           const double* __restrict__ Xr,
                                           const double* __restrict__ Br, double* __restrict__ Yr,
-                                          int ld, cplx w) {
+                                          int ld, cplx w, const double (*xown)[NT] = nullptr) {
   const int c = lane & 15;
   const bool odd = (c & 1) != 0;
   const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
@@ -705,7 +707,7 @@ __device__ __forceinline__ void bsr_store(const sw_double4 (&re)[NT], const sw_d
       if (MODE == 3) {
         const double tt = (NTIO ? __builtin_nontemporal_load(&Br[off]) : Br[off]) - y;
         const double tp = __shfl_xor(tt, 1);
-        y = Xr[off] + w.x * tt + (odd ? w.y * tp : -w.y * tp);
+        y = (xown ? xown[r][t] : Xr[off]) + w.x * tt + (odd ? w.y * tp : -w.y * tp);
       }
       if (NTIO) __builtin_nontemporal_store(y, &Yr[off]);
       else Yr[off] = y;
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(SW_BLOCK, SW_BSR_MIN_WAVES(NT, STG)) void k_bsr_mfm
                                                        const double* __restrict__ Br,
                                                        double* __restrict__ Yr, int ld, int nbp,
                                                        cplx w, int map, int msub,
-                                                       const int* __restrict__ tmap) {
+                                                       const int* __restrict__ tmap, int xreg) {
   // the 4 waves of a workgroup take 4 consecutive row tiles and the SAME 64-probe chunk, so
   // the X rows they share (all of them for a dense operator, the common neighbours for a
   // block stencil) are served once from L2 and then from the CU's L1
@@ -799,7 +801,11 @@ __global__ __launch_bounds__(SW_BLOCK, SW_BSR_MIN_WAVES(NT, STG)) void k_bsr_mfm
   }
 #undef SW_BSR_LOAD
 #undef SW_BSR_MFMA
-  bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
+  // xreg: the operator's diagonal block is its last four k-steps (the packers put it there), so after
+  // the tail re-loads stage s holds the X rows 16 ot + 4 s + (lane >> 4) -- exactly the rows the
+  // smoother update reads, in the accumulator's lane layout: no second trip to memory for x
+  if (MODE == 3 && STG == 4 && xreg) bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w, xx);
+  else bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -159,24 +159,39 @@ inline void bsr_pack(BsrHost& out, int n, const int64_t* indptr, const int32_t* 
     std::vector<int>& g = groups[rt];
     for (int r = rt * 16; r < rt * 16 + 16; ++r)
       for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) g.push_back(indices[q] >> 2);
+    // the four column groups of the diagonal block always take part (zeros where absent) ...
+    for (int d = 0; d < 4; ++d) g.push_back(rt * 4 + d);
     std::sort(g.begin(), g.end());
     g.erase(std::unique(g.begin(), g.end()), g.end());
+    // ... and come LAST, in order: the smoother kernel then finds its own X rows in the operand
+    // registers of the final four k-steps (k_bsr_mfma, xreg)
+    std::vector<int> off, diag;
+    for (int c : g) (c >= rt * 4 && c < rt * 4 + 4 ? diag : off).push_back(c);
+    g = off;
+    g.insert(g.end(), diag.begin(), diag.end());
     KS = std::max(KS, (int)g.size());
   }
   if (KS == 0) return;
-  KS += KS & 1;   // the kernel's two-stage pipeline wants an even number of k-steps
+  KS = (KS + 3) & ~3;   // whole four-stage rounds of the kernel's register pipeline
   const double fill = (double)indptr[n] / ((double)RT * KS * 64.0);
   if (fill < min_fill) return;
   out.kcol.assign((size_t)RT * KS, 0);
   out.vals.assign((size_t)RT * KS * 64, std::complex<double>(0, 0));
+  std::vector<int> slot_of;   // column group -> k-step of this row tile
   for (int rt = 0; rt < RT; ++rt) {
     const std::vector<int>& g = groups[rt];
-    for (size_t k = 0; k < g.size(); ++k) out.kcol[(size_t)rt * KS + k] = g[k] * 4;
+    // padding (zero values, a valid column) sits BEFORE the diagonal block, which stays last
+    const size_t pad = (size_t)KS - g.size(), nd = g.size() - 4;
+    for (size_t k = 0; k < (size_t)KS; ++k) {
+      const size_t src = k < nd ? k : (k < nd + pad ? nd : k - pad);
+      out.kcol[(size_t)rt * KS + k] = g[src] * 4;
+    }
     for (int i = 0; i < 16; ++i) {
       const int r = rt * 16 + i;
       for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
         const int c = indices[q];
-        const size_t k = std::lower_bound(g.begin(), g.end(), c >> 2) - g.begin();
+        size_t k = std::find(g.begin(), g.end(), c >> 2) - g.begin();
+        if (k >= nd) k += pad;
         const int lane = i + 16 * (c & 3);
         out.vals[((size_t)rt * KS + k) * 64 + lane] += data[q];
       }

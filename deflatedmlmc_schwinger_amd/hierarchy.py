@@ -342,10 +342,18 @@ def block_rows_from_matrix(M, row_sites, n):
         blk = Mb.data[lo:hi]                                   # [nb, 16 (i), 16 (col)]
         kcol[r, :] = int(s_) * 16                              # padding: a valid column, zero values
         nbk = hi - lo
-        kcol[r, :nbk * 4] = (cs[:, None] * 16 + 4 * g[None, :]).reshape(-1)
+        # the block of the row's own site goes LAST (after any padding): the smoother kernel then
+        # finds its own X rows in the operand registers of the final four k-steps (k_bsr_mfma, xreg)
+        own = np.flatnonzero(cs == s_)
+        order = np.concatenate([np.flatnonzero(cs != s_), own])
+        cs, blk = cs[order], blk[order]
+        first = np.arange(nbk * 4)
+        if own.size:
+            first[(nbk - 1) * 4:] += (KB - nbk) * 4             # own block into the last four slots
+        kcol[r, first] = (cs[:, None] * 16 + 4 * g[None, :]).reshape(-1)
         # vals[q*4+g, c4*16 + i] = blk[q, i, 4 g + c4]
         b4 = blk.reshape(nbk, 16, 4, 4)                         # [q, i, g, c4]
-        vals[r, :nbk * 4, :] = b4.transpose(0, 2, 3, 1).reshape(nbk * 4, 64)
+        vals[r, first, :] = b4.transpose(0, 2, 3, 1).reshape(nbk * 4, 64)
     return row_sites.astype(np.int32), kcol, vals
 
 

@@ -139,6 +139,10 @@ def level_geometry(Lf, hd, agg, fine_level):
     nbr = np.stack([cs, yc * Lc + (xc + 1) % Lc, yc * Lc + (xc - 1) % Lc,
                     ((yc + 1) % Lc) * Lc + xc, ((yc - 1) % Lc) * Lc + xc], axis=1)
     nbr = np.sort(nbr, axis=1)
+    if Lc > 1:
+        # ... the site itself LAST: the smoother kernel then finds its own X rows in the operand
+        # registers of the final four k-steps (k_bsr_mfma, xreg)
+        nbr = np.concatenate([nbr[nbr != cs[:, None]].reshape(-1, 4), cs[:, None]], axis=1)
     # visit the row groups sorted by their first coarse column: the groups of one aggregate (spread
     # over both parity halves of the even-odd order at level 0) become neighbours in time and L2
     porder = np.argsort(pcols[:, 0], kind="stable")

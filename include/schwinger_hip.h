@@ -112,7 +112,8 @@ int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles);
  *   groups (groups that share coarse columns adjacent).
  * sw_setup_galerkin: A_{level+1} = R A P (multigrid.py:276-280) by 16-colour probing with the
  *   engine's own operator kernels, written straight into MFMA block-row form.  nbr[ncs*5]: the five
- *   sites of each coarse site's 5-point neighbourhood, strictly increasing.
+ *   sites of each coarse site's 5-point neighbourhood, pairwise distinct (the site itself last lets
+ *   the smoother kernel keep its own X rows in registers).
  * sw_get_level_dense: a device-built level operator as a dense row-major complex128[n*n] (for the
  *   host inverse of the coarsest level, multigrid.py:342-344). */
 int sw_setup_testvectors(sw_engine* h, int hid, int level, int nvec, uint64_t seed, int sweeps,

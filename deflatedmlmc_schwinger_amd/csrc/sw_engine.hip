@@ -89,6 +89,10 @@ struct KrylovWS {
   // vector it is applied to next, written by the kernel that produced that vector
   cplxf* Z32 = nullptr;
   cplxf* v32 = nullptr;
+  // option f32_krylov: the whole restart cycle in complex64 storage (basis V32, w = A z written
+  // complex64, inner products accumulated in fp64) -- iterative refinement with GMRES(m) cycles: the
+  // residual b - A x and the solution update stay fp64, once per restart
+  cplxf* V32 = nullptr;
   cplx* xacc = nullptr;
   cplx* rres = nullptr;
   swk::FgScalars sc{};
@@ -174,6 +178,7 @@ struct sw_engine {
   int f32_tiles = 0;          // tiles of 16 probes per wave in k_bsr_mfma_f32 (0: automatic)
   int f32_stages = 4, f32_dense_stages = 8;
   int f32_splitk = 1;         // split-K block-row kernel: 0 off, 1 dense coarsest inverse, 2 every small operator
+  bool f32_krylov = true;     // with precond_f32 on the lattice level: complex64 Krylov basis per restart cycle
   bool f32_pairs = true;      // two probes per lane in the HBM-bound complex64 kernels (A/B switch)
   int mfma_small_tiles = 2;   // tiles per wave for operators too small to fill the chip (0: off)
   // iteration count of the previous outer solve per (hierarchy, level): the convergence flag
@@ -581,8 +586,8 @@ static int stencil_spw(sw_engine* h, int tile_w) {
 
 // the Wilson stencil of the lattice level; CI = complex64: X is a direction stored by the
 // single-precision preconditioner (mode 0 only), widened on load
-template <class CI>
-static int launch_stencil(sw_engine* h, Level& lv, int mode, const CI* X, const cplx* B, cplx* Y,
+template <class CI, class CO>
+static int launch_stencil(sw_engine* h, Level& lv, int mode, const CI* X, const cplx* B, CO* Y,
                           int nbp, cplx w) {
   {
     swk::StencilArgs a;
@@ -606,12 +611,12 @@ static int launch_stencil(sw_engine* h, Level& lv, int mode, const CI* X, const 
     const int nchunks = nbp / 64;
     LaunchScope ls(h, mode == 0 ? T_STENCIL : (mode == 1 ? T_STENCIL_RES : T_STENCIL_SM));
 #define ST_LAUNCH(MD, SP)                                                                       \
-  hipLaunchKernelGGL((swk::k_stencil<MD, SP, CI>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, \
+  hipLaunchKernelGGL((swk::k_stencil<MD, SP, CI, CO>), dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, \
                      X, B, Y, a, bpc)
 #define ST_MODE(SP)                                                  \
   do {                                                               \
     if (mode == 0) ST_LAUNCH(0, SP);                                 \
-    else if constexpr (std::is_same<CI, cplx>::value) {              \
+    else if constexpr (std::is_same<CI, cplx>::value && std::is_same<CO, cplx>::value) { \
       if (mode == 1) ST_LAUNCH(1, SP);                               \
       else ST_LAUNCH(2, SP);                                         \
     } else return sw_fail(h, "internal: complex64 stencil input supports Y = A X only"); \
@@ -630,7 +635,7 @@ static int launch_stencil(sw_engine* h, Level& lv, int mode, const CI* X, const 
 // Y = A X (mode 0), Y = B - A X (mode 1) or Y = X + w (B - A X) (mode 2) at a level
 static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* B, cplx* Y,
                     int nbp, cplx w = cplx{0.0, 0.0}) {
-  if (lv.stencil) return launch_stencil<cplx>(h, lv, mode, X, B, Y, nbp, w);
+  if (lv.stencil) return launch_stencil<cplx, cplx>(h, lv, mode, X, B, Y, nbp, w);
   return launch_ell(h, lv.A, mode == 2 ? 3 : mode, X, B, Y, nbp, T_MVM, w);
 }
 
@@ -649,7 +654,8 @@ static void row_blocking(int n, int nbp, bool reduce, int* P, int* rpb) {
 }
 
 // out[k][col] = sum_r conj(V_k[r]) W[r],  k < K
-static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n, int nbp,
+template <class CV>
+static int multidot(sw_engine* h, const swk::PtrListT<CV>& V, int K, const CV* W, int n, int nbp,
                     cplx* out, const cplx* svec = nullptr, cplx* coef = nullptr) {
   if (K < 1 || K > SW_MAXM + 2) return sw_fail(h, "multidot: K=%d out of range", K);
   int P, rpb;
@@ -659,7 +665,7 @@ static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n,
   {
     LaunchScope ls(h, T_DOTS);
 #define MD_CASE(KT)                                                                             \
-  hipLaunchKernelGGL((swk::k_multidot<KT>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, W, n, nbp, \
+  hipLaunchKernelGGL((swk::k_multidot<KT, CV>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, W, n, nbp, \
                      rpb, h->partial)
     if (K <= 2) MD_CASE(2);
     else if (K <= 4) MD_CASE(4);
@@ -680,9 +686,9 @@ static int multidot(sw_engine* h, const PtrList& V, int K, const cplx* W, int n,
 }
 
 // Wout = Win + sign * sum_k coef[k] V_k ; optional nrm[col].x = ||Wout||^2
-template <class CV>
+template <class CV, class CW>
 static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx* coef, double sign,
-                     const cplx* Win, cplx* Wout, int n, int nbp, cplx* nrm_out,
+                     const CW* Win, CW* Wout, int n, int nbp, cplx* nrm_out,
                      cplxf* w32 = nullptr) {
   if (K < 1 || K > SW_MAXM + 2) return sw_fail(h, "multiaxpy: K=%d out of range", K);
   int P, rpb;
@@ -694,10 +700,10 @@ static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx
 #define MA_CASE(KT)                                                                              \
   do {                                                                                           \
     if (nrm_out)                                                                                 \
-      hipLaunchKernelGGL((swk::k_multiaxpy<KT, true, CV>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, \
+      hipLaunchKernelGGL((swk::k_multiaxpy<KT, true, CV, CW>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, \
                          coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32);                   \
     else                                                                                         \
-      hipLaunchKernelGGL((swk::k_multiaxpy<KT, false, CV>), grid, dim3(SW_BLOCK), 0, h->stream, V, \
+      hipLaunchKernelGGL((swk::k_multiaxpy<KT, false, CV, CW>), grid, dim3(SW_BLOCK), 0, h->stream, V, \
                          K, coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32);                \
   } while (0)
     if (K <= 2) MA_CASE(2);
@@ -761,6 +767,7 @@ static int free_krylov(sw_engine* h, KrylovWS& w) {
   SWCHK(dev_free(h, w.Z)); w.Z = nullptr;
   SWCHK(dev_free(h, w.Z32)); w.Z32 = nullptr;
   SWCHK(dev_free(h, w.v32)); w.v32 = nullptr;
+  SWCHK(dev_free(h, w.V32)); w.V32 = nullptr;
   SWCHK(dev_free(h, w.xacc)); w.xacc = nullptr;
   SWCHK(dev_free(h, w.rres)); w.rres = nullptr;
   SWCHK(dev_free(h, w.sc.H)); w.sc.H = nullptr;
@@ -1523,6 +1530,8 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       SWCHK(dev_realloc(h, &ws.v32, vec));
     }
   }
+  const bool k32 = z32 && h->f32_krylov;
+  if (k32 && !ws.V32) SWCHK(dev_realloc(h, &ws.V32, vec * m));
   while (done < maxiter && !converged) {
     // beta = ||r||
     {
@@ -1537,7 +1546,9 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     // the basis is kept unnormalised (k_fg_hess): vtilde_0 is the residual where it lies,
     // vtilde_{j+1} the orthogonalised A M vtilde_j -- no normalisation passes over the vectors
     auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
+    auto vt32 = [&](int k) -> const cplxf* { return k == 0 ? ws.v32 : ws.V32 + vec * (k - 1); };
     if (z32) SWCHK(cast_vec(h, Rcur, ws.v32, vec, T_AXPY));
+    const bool two_pass = h->cgs2 || (!outer && h->inner_cgs2);
     int j = 0;
     const int jmax = std::min(m, maxiter - done);
     for (; j < jmax; ++j) {
@@ -1545,9 +1556,27 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       cplx* zj = ws.Z + vec * j;
       cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
       cplxf* zj32 = z32 ? ws.Z32 + vec * j : nullptr;
+      if (k32) {
+        // complex64 cycle: vtilde_j -> z_j -> w = A z_j -> orthogonalised vtilde_{j+1}, all stored
+        // complex64 (the arithmetic of A z and of the inner products is fp64 on widened operands)
+        cplxf* w32 = ws.V32 + vec * j;
+        SWCHK(vcycle32(h, H, level, vt32(j), zj32, nbp));
+        SWCHK((launch_stencil<cplxf, cplxf>(h, lv, 0, zj32, nullptr, w32, nbp, cplx{0.0, 0.0})));
+        swk::PtrListT<cplxf> pv32;
+        for (int k = 0; k <= j; ++k) pv32.p[k] = vt32(k);
+        SWCHK(multidot(h, pv32, j + 1, (const cplxf*)w32, n, nbp, ws.h1, ws.sc.svec, ws.c1));
+        if (two_pass) {
+          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, nullptr));
+          SWCHK(multidot(h, pv32, j + 1, (const cplxf*)w32, n, nbp, ws.h2, ws.sc.svec, ws.c1));
+          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm));
+        } else {
+          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm));
+          HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
+        }
+      } else {
       if (z32) {
         SWCHK(vcycle32(h, H, level, ws.v32, zj32, nbp));
-        SWCHK(launch_stencil<cplxf>(h, lv, 0, zj32, nullptr, w, nbp, cplx{0.0, 0.0}));
+        SWCHK((launch_stencil<cplxf, cplx>(h, lv, 0, zj32, nullptr, w, nbp, cplx{0.0, 0.0})));
       } else {
         if (pf32) SWCHK(vcycle_f32_boundary(h, H, level, vj, zj, nbp));
         else if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
@@ -1558,7 +1587,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
       // pass 1: raw dots d1 = Vt^H w, coefficients c = svec^2 d1 ; w -= Vt c
       SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1));
-      if (h->cgs2 || (!outer && h->inner_cgs2)) {
+      if (two_pass) {
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, nullptr));
         // pass 2 (re-orthogonalisation): d2 = Vt^H w ; w -= Vt (svec^2 d2) ; ||w||^2
         SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2, ws.sc.svec, ws.c1));
@@ -1567,6 +1596,7 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
         HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
       }
+      }   // fp64 basis
       if (outer) HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
       {
         LaunchScope ls(h, T_OTHER);
@@ -2468,6 +2498,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "f32_splitk") == 0) {
     h->f32_splitk = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "f32_krylov") == 0) {
+    h->f32_krylov = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "f32_pairs") == 0) {

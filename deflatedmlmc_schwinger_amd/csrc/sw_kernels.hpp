@@ -110,6 +110,9 @@ __device__ __forceinline__ cplxf2 cschur(cplxf2 q, float d, cplxf2 c, float di, 
 }
 __device__ __forceinline__ cplx widen(cplx v) { return v; }
 __device__ __forceinline__ cplx widen(cplxf v) { return cmake((double)v.x, (double)v.y); }
+template <class C> __device__ __forceinline__ C narrow(cplx v);
+template <> __device__ __forceinline__ cplx narrow<cplx>(cplx v) { return v; }
+template <> __device__ __forceinline__ cplxf narrow<cplxf>(cplx v) { return cmake((float)v.x, (float)v.y); }
 template <class C> __device__ __forceinline__ C czero() {
   C r;
   r.x = 0;
@@ -158,10 +161,10 @@ __device__ __forceinline__ size_t eo_row(int x, int y, int L, int Vh) {
 
 // CI: storage type of X (complex64 when X is a direction made by the single-precision
 // preconditioner; widened on load -- the arithmetic is fp64 either way)
-template <int MODE, int SPW, class CI = cplx>
+template <int MODE, int SPW, class CI = cplx, class CO = cplx>
 __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const CI* __restrict__ X,
                                                       const cplx* __restrict__ B,
-                                                      cplx* __restrict__ Y, StencilArgs a,
+                                                      CO* __restrict__ Y, StencilArgs a,
                                                       int blocks_per_chunk) {
   const int nblk = gridDim.x;
   const int bb = xcd_remap(blockIdx.x, nblk);
@@ -233,15 +236,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const CI* __restrict__ X,
       o0 = t0;
       o1 = t1;
     }
-    if (a.nt_store) {
+    if (sizeof(CO) == sizeof(cplx) && a.nt_store) {
       // streaming output: keep it from displacing the neighbour rows held in L2
-      __builtin_nontemporal_store(o0.x, &Y[r_c * nbp + col].x);
-      __builtin_nontemporal_store(o0.y, &Y[r_c * nbp + col].y);
-      __builtin_nontemporal_store(o1.x, &Y[(r_c + 1) * nbp + col].x);
-      __builtin_nontemporal_store(o1.y, &Y[(r_c + 1) * nbp + col].y);
+      double* y0 = (double*)&Y[r_c * nbp + col];
+      double* y1 = (double*)&Y[(r_c + 1) * nbp + col];
+      __builtin_nontemporal_store(o0.x, y0);
+      __builtin_nontemporal_store(o0.y, y0 + 1);
+      __builtin_nontemporal_store(o1.x, y1);
+      __builtin_nontemporal_store(o1.y, y1 + 1);
     } else {
-      Y[r_c * nbp + col] = o0;
-      Y[(r_c + 1) * nbp + col] = o1;
+      Y[r_c * nbp + col] = narrow<CO>(o0);
+      Y[(r_c + 1) * nbp + col] = narrow<CO>(o1);
     }
     // slide the window
     l0 = c0; l1 = c1;
@@ -1343,8 +1348,10 @@ struct PtrListT {
 typedef PtrListT<cplx> PtrList;
 
 // partial[(blockIdx.x*K + k)*nbp + col] = sum over this block's rows of conj(V_k[r]) * W[r]
-template <int KT>
-__global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrList V, int K, const cplx* __restrict__ W,
+// CV: storage type of V and W (complex64 for the Krylov basis of the single-precision cycle mode);
+// products and sums are fp64 either way
+template <int KT, class CV = cplx>
+__global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrListT<CV> V, int K, const CV* __restrict__ W,
                                                        int n, int nbp, int rows_per_block,
                                                        cplx* __restrict__ partial) {
   __shared__ cplx red[3][8][64];
@@ -1358,10 +1365,10 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrList V, int K, const c
 #pragma unroll 2
   for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
     const size_t off = (size_t)r * nbp + col;
-    const cplx w = W[off];
+    const cplx w = widen(W[off]);
 #pragma unroll
     for (int k = 0; k < KT; ++k)
-      if (k < K) cfmac(acc[k], V.p[k][off], w);
+      if (k < K) cfmac(acc[k], widen(V.p[k][off]), w);
   }
   // cross-wave reduction, 8 accumulators at a time
   for (int kb = 0; kb < KT; kb += 8) {
@@ -1437,11 +1444,12 @@ __global__ __launch_bounds__(SW_BLOCK) void k_reduce_partials(const cplx* __rest
 // CV: storage type of the V vectors (complex64 for the preconditioned directions Z of the
 // single-precision preconditioner, widened on load); W32 (optional): complex64 copy of Wout, the
 // next input of that preconditioner.
-template <int KT, bool NORM, class CV = cplx>
+// CW: storage type of Win / Wout (complex64 when W is itself a vector of a complex64 Krylov basis).
+template <int KT, bool NORM, class CV = cplx, class CW = cplx>
 __global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrListT<CV> V, int K,
                                                         const cplx* __restrict__ coef, double sign,
-                                                        const cplx* __restrict__ Win,
-                                                        cplx* __restrict__ Wout, int n, int nbp,
+                                                        const CW* __restrict__ Win,
+                                                        CW* __restrict__ Wout, int n, int nbp,
                                                         int rows_per_block,
                                                         cplx* __restrict__ partial,
                                                         cplxf* __restrict__ W32) {
@@ -1463,14 +1471,11 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrListT<CV> V, int K,
 #pragma unroll 2
   for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
     const size_t off = (size_t)r * nbp + col;
-    cplx w = Win[off];
+    cplx w = widen(Win[off]);
 #pragma unroll
     for (int k = 0; k < KT; ++k)
-      if (k < K) {
-        const CV v = V.p[k][off];
-        cfma(w, c[k], cmake((double)v.x, (double)v.y));
-      }
-    Wout[off] = w;
+      if (k < K) cfma(w, c[k], widen(V.p[k][off]));
+    Wout[off] = narrow<CW>(w);
     if (W32) W32[off] = cmake((float)w.x, (float)w.y);
     if (NORM) nrm = fma(w.x, w.x, fma(w.y, w.y, nrm));
   }

@@ -448,12 +448,12 @@ DEFAULT_SOLVER_CFG = {
 
 # The benchmark's hierarchy for schwinger128 (bench.py; any L with L/16 a multiple of 4): one more
 # coarsening than the default, so the dense inverse shrinks from 4096^2 to 1024^2 and the 4096-row
-# level is smoothed by 16 polynomial steps instead; built entirely on the GPU (setup_gpu.py).
-# 128^2, one MI355X (3 streams): 16k probe-samples/s, 11-12 outer iterations with every level smoothed
+# level is smoothed instead; built entirely on the GPU (setup_gpu.py).
+# 128^2, one MI355X (3 streams): 18k probe-samples/s, 10 outer iterations with every level smoothed
 # even-odd (12.2k with level 0 only, 9.9k / 14 iterations without; 8.8k for DEFAULT_SOLVER_CFG).
 TUNED_SOLVER_CFG_128 = {
     "coarsening": [(4, 8), (2, 8), (2, 8)],
-    "cycle": [(0, 6, 0), (0, 5, 0), (0, 14, 0)],
+    "cycle": [(0, 8, 0), (0, 5, 0), (0, 14, 0)],
     "smoother": "richardson",
     "eo_levels": [0, 1, 2],     # levels smoothed on their even-odd Schur complement (half vectors)
     "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count

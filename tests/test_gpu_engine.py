@@ -972,11 +972,16 @@ def test_single_precision_preconditioner_keeps_fp64_results(p128, kcycle):
             X = p.eng.vcycle(SOLVER_HID, level0, B.T.copy())
             err = _relerr(X, ref)
             assert 1e-9 < err < 2e-5, (level0, err)      # single precision, and really single precision
-        ests, its, _ = p.eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
-        for k in range(0, 70, 7):
-            ref_e = rp.hutch_probe(probes[k].astype(np.complex128), lu, p.Ux, PT)
-            assert abs(ests[k] - ref_e) / abs(ref_e) < 1e-10
-        assert abs(int(its.max()) - int(its64.max())) <= 2, (its.max(), its64.max())
+        # f32_krylov = 1 (default): the restart cycles keep their Krylov basis in complex64 as well
+        # (iterative refinement: residual and solution update in fp64 once per restart); 0: fp64 basis
+        for fk in (1, 0):
+            p.eng.set_option("f32_krylov", fk)
+            ests, its, _ = p.eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+            for k in range(0, 70, 7):
+                ref_e = rp.hutch_probe(probes[k].astype(np.complex128), lu, p.Ux, PT)
+                assert abs(ests[k] - ref_e) / abs(ref_e) < 1e-10, (fk, k)
+            assert abs(int(its.max()) - int(its64.max())) <= 2, (fk, its.max(), its64.max())
     finally:
+        p.eng.set_option("f32_krylov", 1)
         p.eng.set_option("precond_f32", 0)
         p.mg.upload_solver_hierarchy(None)

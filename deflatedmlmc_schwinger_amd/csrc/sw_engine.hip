@@ -639,11 +639,16 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
   return launch_ell(h, lv.A, mode == 2 ? 3 : mode, X, B, Y, nbp, T_MVM, w);
 }
 
+// Workgroups of a reducing BLAS-1 launch (row blocks x probe chunks; option dot_blocks).  Round 1's cap of
+// 128 row blocks left a 64-probe batch on a 1024^2 lattice with 512 waves for 2 M rows: 1024 blocks took
+// its inner products from 61.7 to 20.7 ms and the fused-norm updates from 61.7 to 30.2 ms per batch
+// (165 -> 214 probe-samples/s); beyond ~1500 the second reduction stage grows faster than the first shrinks.
+static int g_dot_blocks = 1024, g_dot_pmax = 1024;
 static void row_blocking(int n, int nbp, bool reduce, int* P, int* rpb) {
   const int nchunks = nbp / 64;
   int p;
   if (reduce) {
-    p = std::max(8, std::min(128, 512 / std::max(1, nchunks)));
+    p = std::max(8, std::min(g_dot_pmax, g_dot_blocks / std::max(1, nchunks)));
   } else {
     p = std::max(8, 4096 / std::max(1, nchunks));
   }
@@ -2498,6 +2503,11 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "f32_splitk") == 0) {
     h->f32_splitk = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "dot_blocks") == 0) {
+    g_dot_blocks = std::max(64, (int)value);
+    g_dot_pmax = g_dot_blocks;
     return 0;
   }
   if (std::strcmp(name, "f32_krylov") == 0) {

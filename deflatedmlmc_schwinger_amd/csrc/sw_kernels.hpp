@@ -1362,7 +1362,9 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrListT<CV> V, int K, co
   cplx acc[KT];
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc[k] = cmake(0.0, 0.0);
-#pragma unroll 2
+  // complex64 rows are half as wide: twice the rows in flight for the same bytes in flight
+  constexpr int UNR = (sizeof(CV) == sizeof(cplxf)) ? 4 : 2;
+#pragma unroll UNR
   for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
     const size_t off = (size_t)r * nbp + col;
     const cplx w = widen(W[off]);
@@ -1468,7 +1470,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrListT<CV> V, int K,
     }
   }
   double nrm = 0.0;
-#pragma unroll 2
+  constexpr int UNR = (sizeof(CV) == sizeof(cplxf) && sizeof(CW) == sizeof(cplxf)) ? 4 : 2;
+#pragma unroll UNR
   for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
     const size_t off = (size_t)r * nbp + col;
     cplx w = widen(Win[off]);

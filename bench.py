@@ -53,7 +53,7 @@ def parse():
                          "headline metric); mlmc: level-0 MLMC difference probes with level "
                          "skipping, A0^-1 - P0 P1 A2^-1 R1 R0 (config 3); synthetic: plain Hutchinson "
                          "probes on a synthetic random-gauge --lattice^2 configuration with the "
-                         "GPU-side setup (config 5; use --nb 64 and --streams 1 or 2 at 1024: 74 / 95 probe-samples/s); "
+                         "GPU-side setup (config 5; use --nb 64 and --streams 1 or 2 at 1024); "
                          "config2: BASELINE config 2 AS WRITTEN -- plain (k=0) Hutchinson probes, "
                          "2-level multigrid 32768 -> 8192 built with the reference's aggregation "
                          "(32-row aggregates, 4 test vectors x 2), dense 8192^2 coarse inverse")

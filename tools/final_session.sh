@@ -8,9 +8,12 @@ timeout -k 10 300 python3 bench.py --workload mlmc --steps 6 --warmup 2 --no-lar
 for L in 512 1024; do
   timeout -k 10 400 python3 bench.py --workload synthetic --lattice $L --nb 64 --streams 1 --steps 3 --warmup 1 > gpurun_out/r02_synth$L.json 2> gpurun_out/r02_synth$L.err
 done
+timeout -k 10 400 python3 bench.py --workload synthetic --lattice 1024 --nb 64 --streams 2 --steps 3 --warmup 1 --no-large-stencil > gpurun_out/r02_synth1024_s2.json 2> gpurun_out/r02_synth1024_s2.err
 python3 - <<'PY'
 import json
-for f in ("r02/bench", "r02_bench_config2", "r02_bench_mlmc", "r02_synth512", "r02_synth1024"):
+for f in ("r02/bench", "r02_bench_config2", "r02_bench_mlmc", "r02_synth512", "r02_synth1024", "r02_synth1024_s2"):
     d = json.load(open("gpurun_out/%s.json" % f))
-    print(f, round(d["value"], 1), d["config"]["outer_iterations_max"], d["roofline"]["kernel"], round(d["roofline"]["frac"], 3))
+    f32 = d.get("f32_preconditioner") or {}
+    print(f, round(d["value"], 1), d["config"]["outer_iterations_max"], d["roofline"]["kernel"], round(d["roofline"]["frac"], 3),
+          "f32:", round(f32.get("value", 0.0), 1), f32.get("outer_iterations_max"))
 PY

@@ -9,18 +9,19 @@ import sys
 
 
 def short(name):
-    name = name.replace("HIP_vector_type<double, 2u>", "cplx")
+    name = name.replace("HIP_vector_type<double, 2u>", "cplx").replace("HIP_vector_type<float, 2u>", "cplxf")
     return name.split("(")[0].replace("void ", "")[:70]
 
 
-def main(out):
+def main(out, extra=""):
     lines = []
     newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]      # gpurun merges runs into one tree
     stats = newest(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --streams 1 --no-large-stencil --no-cpu-baseline")
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --streams 1 "
+                     "--no-large-stencil --no-cpu-baseline --no-f32-line" + extra)
         lines.append("%-72s %7s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
         for r in rows[:24]:
             lines.append("%-72s %7d %12.3f %10.2f %6.2f" % (
@@ -90,4 +91,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], " " + " ".join(sys.argv[2:]) if len(sys.argv) > 2 else "")

@@ -643,12 +643,15 @@ static int apply_op(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx
 // 128 row blocks left a 64-probe batch on a 1024^2 lattice with 512 waves for 2 M rows: 1024 blocks took
 // its inner products from 61.7 to 20.7 ms and the fused-norm updates from 61.7 to 30.2 ms per batch
 // (165 -> 214 probe-samples/s); beyond ~1500 the second reduction stage grows faster than the first shrinks.
+// With four or more probe chunks 128 row blocks already make 512+ workgroups, and the second stage
+// (k_reduce_partials: 5 us at 128 partials, 17 us at 256) would eat what the first gains.
 static int g_dot_blocks = 1024, g_dot_pmax = 1024;
 static void row_blocking(int n, int nbp, bool reduce, int* P, int* rpb) {
   const int nchunks = nbp / 64;
   int p;
   if (reduce) {
     p = std::max(8, std::min(g_dot_pmax, g_dot_blocks / std::max(1, nchunks)));
+    if (nchunks >= 4 && g_dot_pmax == 1024) p = std::min(p, 128);
   } else {
     p = std::max(8, 4096 / std::max(1, nchunks));
   }

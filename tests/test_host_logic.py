@@ -347,3 +347,50 @@ def test_device_setup_geometry_reproduces_the_host_prolongator(Lf, hd, agg, fine
     nbr = g["nbr"]
     col = (nbr % Lc) % 4 + 4 * ((nbr // Lc) % 4)
     assert all(len(set(r)) == 5 for r in nbr.tolist()) and all(len(set(r)) == 5 for r in col.tolist())
+
+
+def test_block_row_packers_put_the_own_site_block_last():
+    """The smoother kernel reads its own X rows from the operand registers of the last four k-steps
+    (k_bsr_mfma, xreg): hierarchy.block_rows_from_matrix and setup_gpu.level_geometry must put the
+    block / neighbour of the row's own site last, and the packed form must still be the matrix."""
+    import scipy.sparse as sp
+    from deflatedmlmc_schwinger_amd import hierarchy, setup_gpu
+    rng = np.random.default_rng(5)
+    Lc = 4
+    ns, n = Lc * Lc, Lc * Lc * 16
+    site = np.arange(ns)
+    x, y = site % Lc, site // Lc
+    blocks = {}
+    for s_ in site:
+        for t in {int(s_), int(y[s_] * Lc + (x[s_] + 1) % Lc), int(y[s_] * Lc + (x[s_] - 1) % Lc),
+                  int(((y[s_] + 1) % Lc) * Lc + x[s_]), int(((y[s_] - 1) % Lc) * Lc + x[s_])}:
+            blocks[(int(s_), t)] = rng.standard_normal((16, 16)) + 1j * rng.standard_normal((16, 16))
+    A = sp.bmat([[blocks.get((i, j)) for j in range(ns)] for i in range(ns)], format="csr")
+    rows = np.arange(0, ns, 2)
+    tmap, kcol, vals = hierarchy.block_rows_from_matrix(A, rows, n)
+    KS = kcol.shape[1]
+    assert KS % 4 == 0
+    for r, s_ in enumerate(rows):
+        assert list(kcol[r, KS - 4:]) == [16 * s_ + 4 * g for g in range(4)]
+    xv = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ref = A @ xv
+    for r, s_ in enumerate(rows):
+        acc = np.zeros(16, dtype=complex)
+        for k in range(KS):
+            for c in range(4):
+                acc += vals[r, k, 16 * c:16 * c + 16] * xv[kcol[r, k] + c]
+        assert abs(acc - ref[16 * s_:16 * s_ + 16]).max() < 1e-12
+        assert tmap[r] == s_
+    g = setup_gpu.level_geometry(32, 1, 4, True)
+    nbr = g["nbr"]
+    assert (nbr[:, 4] == np.arange(nbr.shape[0])).all()
+    assert all(len(set(row)) == 5 for row in nbr)
+
+
+def test_f32_capable_configurations():
+    from deflatedmlmc_schwinger_amd import hierarchy
+    assert hierarchy.f32_capable(hierarchy.TUNED_SOLVER_CFG_128)
+    assert not hierarchy.f32_capable(hierarchy.DEFAULT_SOLVER_CFG)             # level 0 not even-odd
+    assert hierarchy.f32_capable(dict(hierarchy.TUNED_SOLVER_CFG_128, cycle=[(0, 6, 0), (0, 5, 2), (0, 9, 0)]))
+    assert not hierarchy.f32_capable(dict(hierarchy.TUNED_SOLVER_CFG_128, cycle=[(2, 6, 0), (0, 5, 0), (0, 9, 0)]))
+    assert not hierarchy.f32_capable(dict(hierarchy.TUNED_SOLVER_CFG_128, smoother="mr"))

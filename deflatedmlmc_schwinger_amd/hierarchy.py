@@ -416,9 +416,134 @@ def f32_capable(cfg):
     return all(int(c[0]) == 0 for c in cfg["cycle"])
 
 
+def site_blocks_of(A, Lc):
+    """(nbr[ns, 5], blk[ns, 5, 16, 16]) of a block level's 5-point operator, or None when the matrix
+    does not have exactly five 16 x 16 blocks in every block row (tiny lattices: general path)."""
+    Ab = sp.bsr_matrix(sp.csr_matrix(A), blocksize=(16, 16))
+    Ab.sort_indices()
+    ns = Lc * Lc
+    if Ab.shape[0] != ns * 16 or not np.all(np.diff(Ab.indptr) == 5):
+        return None
+    return Ab.indices.reshape(ns, 5).astype(np.int64), Ab.data.reshape(ns, 5, 16, 16)
+
+
+def site_blocks_from_block_rows(kcol, vals):
+    """The same from the engine's block-row form of a full level operator (sw_get_level_bsr: 20 k-steps
+    per row tile = 5 site blocks x 4 column groups; vals[rt, 4 q + g, 16 c4 + i] = blk[rt, q, i, 4 g + c4])."""
+    RT, KS = kcol.shape
+    if KS != 20:
+        return None
+    nbr = (kcol[:, ::4] // 16).astype(np.int64)
+    blk = np.asarray(vals).reshape(RT, 5, 4, 4, 16).transpose(0, 1, 4, 2, 3).reshape(RT, 5, 16, 16)
+    return nbr, blk
+
+
+def pack_site_blocks(blocks, targets):
+    """blocks[R, nb, 16, 16] acting on the sites targets[R, nb] -> (kcol[R, 4 nb], vals[R, 4 nb, 64])
+    of the MFMA block-row form (inverse of site_blocks_from_block_rows)."""
+    R, nb = targets.shape
+    g = np.arange(4)
+    kcol = (targets[:, :, None] * 16 + 4 * g[None, None, :]).reshape(R, nb * 4).astype(np.int32)
+    vals = blocks.reshape(R, nb, 16, 4, 4).transpose(0, 1, 3, 4, 2).reshape(R, nb * 4, 64)
+    return kcol, np.ascontiguousarray(vals)
+
+
+def coarse_schur_blocks(nbr, blk, Lc):
+    """Even-odd Schur construction of a block level with batched 16 x 16 algebra (no sparse products,
+    no per-site Python loops): the same S, F, G, Hb as coarse_schur_operators, directly in block-row
+    form, for Lc >= 8 (displacements of +-2 must not alias on the periodic lattice).  Returns a dict with
+    the packed operators [(tmap, kcol, vals) x 4], the site / row lists and S_ee as a sparse matrix
+    over the even rows (for the smoother polynomial)."""
+    ns = Lc * Lc
+    site = np.arange(ns)
+    xs, ys = site % Lc, site // Lc
+    even = ((xs + ys) & 1) == 0
+    is_self = nbr == site[:, None]
+    if Lc < 8 or not np.all(is_self.sum(axis=1) == 1):
+        return None
+    order = np.argsort(is_self, axis=1, kind="stable")          # the four hops first, the site itself last
+    nbr = np.take_along_axis(nbr, order, axis=1)
+    blk = blk[site[:, None], order]
+    hop, hop_to, diag = blk[:, :4], nbr[:, :4], blk[:, 4]
+    if even[hop_to[even]].any() or not even[hop_to[~even]].all():
+        return None                                                # not a nearest-neighbour operator
+    E, O = site[even], site[~even]
+    ginv = np.zeros((ns, 16, 16), dtype=np.complex128)
+    ginv[O] = np.linalg.inv(diag[O])
+    half = Lc // 2
+    disp = [(2, 0), (-2, 0), (0, 2), (0, -2), (1, 1), (1, -1), (-1, 1), (-1, -1), (0, 0)]   # own site LAST
+    lut = np.full((5, 5), -1)
+    for q, (a, b) in enumerate(disp):
+        lut[a + 2, b + 2] = q
+
+    def even_chunk(Ec):
+        """S and F block rows of the even sites Ec (packed), or None on an unexpected geometry."""
+        F = hop[Ec] @ ginv[hop_to[Ec]]                              # [nc, 4]: A_eo D_oo^-1, onto hop_to[Ec]
+        # S = D_ee - sum over the odd neighbours o of F(e, o) A(o, t): nine even targets t per e
+        odd_nb = hop_to[Ec]                                         # [nc, 4]
+        tgt = hop_to[odd_nb]                                        # [nc, 4, 4]
+        prod = F[:, :, None] @ hop[odd_nb]                          # [nc, 4, 4, 16, 16]
+        dx = (xs[tgt] - xs[Ec][:, None, None] + half) % Lc - half
+        dy = (ys[tgt] - ys[Ec][:, None, None] + half) % Lc - half
+        slot = lut[np.clip(dx, -2, 2) + 2, np.clip(dy, -2, 2) + 2]
+        if (slot < 0).any() or (np.abs(dx) > 2).any() or (np.abs(dy) > 2).any():
+            return None
+        Sb = np.zeros((Ec.size, 9, 16, 16), dtype=np.complex128)
+        Sb[:, 8] = diag[Ec]
+        rows = np.arange(Ec.size)
+        for j in range(4):
+            for jp in range(4):
+                Sb[rows, slot[:, j, jp]] -= prod[:, j, jp]          # one target per (e, j, jp): no clashes
+        s_to = np.stack([((ys[Ec] + b) % Lc) * Lc + (xs[Ec] + a) % Lc for (a, b) in disp], axis=1)
+        return Sb, s_to, pack_site_blocks(Sb, s_to), pack_site_blocks(F, hop_to[Ec])
+
+    def odd_chunk(Oc):
+        Hb = ginv[Oc][:, None] @ hop[Oc]                            # [nc, 4]: D_oo^-1 A_oe, onto hop_to[Oc]
+        return pack_site_blocks(ginv[Oc][:, None], Oc[:, None]), pack_site_blocks(Hb, hop_to[Oc])
+
+    # batched 16 x 16 products release the GIL: chunks of sites on a few host threads
+    import concurrent.futures as cf
+    import os
+    nthr = max(1, min(16, (os.cpu_count() or 1)))
+    nchunk = max(1, min(4 * nthr, E.size // 256))
+    with cf.ThreadPoolExecutor(max_workers=nthr) as pool:
+        ev = list(pool.map(even_chunk, np.array_split(E, nchunk)))
+        od = list(pool.map(odd_chunk, np.array_split(O, nchunk)))
+    if any(r is None for r in ev):
+        return None
+    ne = E.size
+    Sb = np.concatenate([r[0] for r in ev])
+    s_to = np.concatenate([r[1] for r in ev])
+    cat = lambda parts: (np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts]))   # noqa: E731
+    packed = [(E.astype(np.int32),) + cat([r[2] for r in ev]),
+              (E.astype(np.int32),) + cat([r[3] for r in ev]),
+              (O.astype(np.int32),) + cat([r[0] for r in od]),
+              (O.astype(np.int32),) + cat([r[1] for r in od])]
+    erank = np.full(ns, -1)
+    erank[E] = np.arange(ne)
+    S_ee = sp.bsr_matrix((Sb.reshape(-1, 16, 16), erank[s_to].reshape(-1), np.arange(0, 9 * ne + 1, 9)),
+                         shape=(ne * 16, ne * 16))
+    row_even = np.repeat(even, 16)
+    return {"packed": packed, "S_ee": S_ee, "E_sites": E, "O_sites": O,
+            "E_rows": np.nonzero(row_even)[0], "O_rows": np.nonzero(~row_even)[0]}
+
+
 def upload_coarse_eo(engines, hid, level, A_l, Lc, degree):
     """Build the four even-odd operators of block level `level` on the host, hand them to the engines
-    and select `degree` Schur steps as its post-smoother.  Returns (weights, ops)."""
+    and select `degree` Schur steps as its post-smoother.  A_l: the level operator as a sparse matrix,
+    or its block-row form (kcol, vals) as sw_get_level_bsr returns it.  Returns (weights, ops)."""
+    sb = site_blocks_from_block_rows(*A_l) if isinstance(A_l, tuple) else site_blocks_of(A_l, Lc)
+    ops = coarse_schur_blocks(sb[0], sb[1], Lc) if sb is not None else None
+    if ops is not None:
+        weights = smoother_weights(ops["S_ee"], degree)
+        for eng in engines:
+            for which, (tmap, kcol, vals) in enumerate(ops["packed"]):
+                eng.set_eo_operator(hid, level, which, tmap, kcol, vals)
+            eng.set_eo_smoother(hid, level, weights)
+        return weights, ops
+    # general path (tiny or irregular lattices): sparse products and per-site packing
+    if isinstance(A_l, tuple):
+        A_l = matrix_from_block_rows(A_l[0], A_l[1], A_l[0].shape[0] * 16)
     ops = coarse_schur_operators(A_l, Lc)
     n = A_l.shape[0]
     packed = [block_rows_from_matrix(ops["S"], ops["E_sites"], n),

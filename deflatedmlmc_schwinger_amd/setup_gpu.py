@@ -271,9 +271,8 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                     elif lv in eo_levels:
                         # block level: its operator comes back in block-row form, the four even-odd
                         # operators are formed on the host (batched 16 x 16 algebra) and uploaded
-                        kcol, vals = eng.level_bsr(hid, lv)
-                        A_l = _hier.matrix_from_block_rows(kcol, vals, sizes[lv])
-                        _hier.upload_coarse_eo([eng], hid, lv, A_l, geo[lv - 1]["Lc"], cyc[1])
+                        _hier.upload_coarse_eo([eng], hid, lv, eng.level_bsr(hid, lv), geo[lv - 1]["Lc"],
+                                               cyc[1])
 
     eng.hier_begin(hid, nl)
     eng.set_lattice(hid, L, mass, U1, U2)

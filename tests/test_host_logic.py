@@ -394,3 +394,46 @@ def test_f32_capable_configurations():
     assert hierarchy.f32_capable(dict(hierarchy.TUNED_SOLVER_CFG_128, cycle=[(0, 6, 0), (0, 5, 2), (0, 9, 0)]))
     assert not hierarchy.f32_capable(dict(hierarchy.TUNED_SOLVER_CFG_128, cycle=[(2, 6, 0), (0, 5, 0), (0, 9, 0)]))
     assert not hierarchy.f32_capable(dict(hierarchy.TUNED_SOLVER_CFG_128, smoother="mr"))
+
+
+def test_batched_even_odd_schur_construction_equals_the_sparse_one():
+    """hierarchy.coarse_schur_blocks (batched 16 x 16 algebra straight into block-row form) against
+    hierarchy.coarse_schur_operators (sparse products) on a random 5-point block operator, through the
+    packed form: S (own block last), F, G, Hb and the compressed S_ee used for the smoother polynomial;
+    plus the round trip between site blocks and the engine's block-row layout."""
+    import scipy.sparse as sp
+    from deflatedmlmc_schwinger_amd import hierarchy as H
+    rng = np.random.default_rng(3)
+    Lc = 8
+    ns, n = Lc * Lc, Lc * Lc * 16
+    site = np.arange(ns)
+    x, y = site % Lc, site // Lc
+    blocks = {}
+    for s_ in site:
+        for t in [int(s_), int(y[s_] * Lc + (x[s_] + 1) % Lc), int(y[s_] * Lc + (x[s_] - 1) % Lc),
+                  int(((y[s_] + 1) % Lc) * Lc + x[s_]), int(((y[s_] - 1) % Lc) * Lc + x[s_])]:
+            b = rng.standard_normal((16, 16)) + 1j * rng.standard_normal((16, 16))
+            blocks[(int(s_), t)] = b + (8 * np.eye(16) if t == s_ else 0)
+    A = sp.bmat([[blocks.get((i, j)) for j in range(ns)] for i in range(ns)], format="csr")
+    old = H.coarse_schur_operators(A, Lc)
+    nbr, blk = H.site_blocks_of(A, Lc)
+    new = H.coarse_schur_blocks(nbr, blk, Lc)
+    assert new is not None
+
+    def unpack(tmap, kcol, vals):
+        RT, KS = kcol.shape
+        r = np.repeat(tmap.astype(np.int64) * 16, KS * 64).reshape(RT, KS, 4, 16) + np.arange(16)
+        c = kcol.astype(np.int64)[:, :, None, None] + np.arange(4)[None, None, :, None] + np.zeros((1, 1, 1, 16), int)
+        v = vals.reshape(RT, KS, 4, 16)
+        return sp.csr_matrix((v.ravel(), (r.ravel(), c.ravel())), shape=(n, n))
+
+    for name, pk in zip(("S", "F", "G", "Hb"), new["packed"]):
+        assert abs(unpack(*pk) - old[name]).max() < 1e-12, name
+    E = old["E_rows"]
+    assert abs(new["S_ee"] - old["S"][E][:, E]).max() < 1e-12
+    assert (new["E_rows"] == old["E_rows"]).all() and (new["O_rows"] == old["O_rows"]).all()
+    tm, kc, _ = new["packed"][0]
+    assert all(list(kc[r, -4:]) == [16 * tm[r] + 4 * g for g in range(4)] for r in range(len(tm)))
+    kcA, vlA = H.pack_site_blocks(blk, nbr)
+    nbr2, blk2 = H.site_blocks_from_block_rows(kcA, vlA)
+    assert (nbr2 == nbr).all() and abs(blk2 - blk).max() == 0.0

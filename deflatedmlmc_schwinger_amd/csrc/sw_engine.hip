@@ -2361,6 +2361,219 @@ int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int 
   return 0;
 }
 
+// The four even-odd operators of a block level built ON THE DEVICE from its operator in block-row form
+// (5-point stencil of 16 x 16 blocks, own site last -- what sw_setup_galerkin produces):
+//   G = D_oo^-1 (k_block_inverse),  F = A_eo G,  Hb = G A_oe,  S = D_ee - F A_oe (k_block_products);
+// the index structure is derived here from the operator's own k-step columns.
+int sw_setup_eo_operators(sw_engine* h, int hid, int level, int Lc) {
+  SWCHK(check_hier(h, hid, level, false));
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  H.f32_valid = H.even_valid = false;
+  Level& lv = H.lv[level];
+  const int ns = Lc * Lc;
+  if (lv.stencil || Lc < 8 || (Lc & 1) || lv.n != ns * 16)
+    return sw_fail(h, "level %d is not a block level of %d x %d sites (extent even, >= 8)", level, Lc, Lc);
+  const EllOp& A = lv.A;
+  if (!A.set || A.bsr_KS != 20 || !A.bsr_vals || !A.bsr_kcol || A.bsr_tmap)
+    return sw_fail(h, "level %d has no 5-point block-row operator (20 k-steps per site)", level);
+  std::vector<int> kc((size_t)ns * 20);
+  HIPCHK(hipMemcpy(kc.data(), A.bsr_kcol, kc.size() * sizeof(int), hipMemcpyDeviceToHost));
+  // nbr[s][j]: the site block j of row site s acts on; the own site must be block 4
+  std::vector<int> nbr((size_t)ns * 5);
+  auto parity = [&](int s) { return ((s % Lc) + (s / Lc)) & 1; };
+  for (int s = 0; s < ns; ++s)
+    for (int j = 0; j < 5; ++j) {
+      const int t = kc[(size_t)s * 20 + 4 * j] / 16;
+      for (int g = 0; g < 4; ++g)
+        if (kc[(size_t)s * 20 + 4 * j + g] != 16 * t + 4 * g)
+          return sw_fail(h, "level %d: k-step columns are not whole site blocks", level);
+      if (t < 0 || t >= ns || (j == 4 ? t != s : parity(t) == parity(s)))
+        return sw_fail(h, "level %d: not a nearest-neighbour operator with the own site last", level);
+      nbr[(size_t)s * 5 + j] = t;
+    }
+  std::vector<int> E, O, rank(ns);
+  for (int s = 0; s < ns; ++s) {
+    std::vector<int>& v = parity(s) ? O : E;
+    rank[s] = (int)v.size();
+    v.push_back(s);
+  }
+  const int ne = (int)E.size(), no = (int)O.size();
+  // the nine even targets of S, own site LAST (k_bsr_mfma's register shortcut)
+  static const int disp[9][2] = {{2, 0}, {-2, 0}, {0, 2}, {0, -2}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}, {0, 0}};
+  auto site_at = [&](int s, int dx, int dy) {
+    const int x = ((s % Lc) + dx + Lc) % Lc, y = ((s / Lc) + dy + Lc) % Lc;
+    return y * Lc + x;
+  };
+  auto slot_of = [&](int e, int t) {
+    for (int q = 0; q < 9; ++q)
+      if (site_at(e, disp[q][0], disp[q][1]) == t) return q;
+    return -1;
+  };
+  struct Built {
+    std::vector<int> tmap, kcol;
+    int KS;
+  };
+  auto shape = [&](const std::vector<int>& rows, int nblk, auto&& target) {
+    Built b;
+    b.KS = 4 * nblk;
+    b.tmap = rows;
+    b.kcol.resize(rows.size() * (size_t)b.KS);
+    for (size_t r = 0; r < rows.size(); ++r)
+      for (int q = 0; q < nblk; ++q)
+        for (int g = 0; g < 4; ++g) b.kcol[r * b.KS + 4 * q + g] = 16 * target((int)r, q) + 4 * g;
+    return b;
+  };
+  Built bS = shape(E, 9, [&](int r, int q) { return site_at(E[r], disp[q][0], disp[q][1]); });
+  Built bF = shape(E, 4, [&](int r, int q) { return nbr[(size_t)E[r] * 5 + q]; });
+  Built bG = shape(O, 1, [&](int r, int) { return O[r]; });
+  Built bH = shape(O, 4, [&](int r, int q) { return nbr[(size_t)O[r] * 5 + q]; });
+  Built* built[4] = {&bS, &bF, &bG, &bH};
+  for (int w = 0; w < 4; ++w) {
+    EllOp& op = lv.eo_op[w];
+    SWCHK(free_op(h, op));
+    op.nrows = op.ncols = lv.n;
+    op.bsr_RT = (int)built[w]->tmap.size();
+    op.bsr_KS = built[w]->KS;
+    SWCHK(upload(h, &op.bsr_tmap, built[w]->tmap.data(), built[w]->tmap.size()));
+    SWCHK(upload(h, &op.bsr_kcol, built[w]->kcol.data(), built[w]->kcol.size()));
+    SWCHK(dev_realloc(h, &op.bsr_vals, (size_t)op.bsr_RT * op.bsr_KS * 64));
+    op.set = true;
+    check_diag_last(op, built[w]->kcol.data(), built[w]->tmap.data());
+  }
+  const cplx* Av = A.bsr_vals;
+  auto ablk = [](int s, int j) { return ((long long)s * 20 + 4 * j) * 64; };          // block j of row site s in A
+  auto oblk = [](int r, int nblk, int q) { return ((long long)r * nblk + q) * 256; };   // block q of row r
+  int* info = nullptr;
+  SWCHK(dev_realloc(h, &info, (size_t)1));
+  HIPCHK(hipMemsetAsync(info, 0, sizeof(int), h->stream));
+  // G
+  {
+    std::vector<long long> so(no), dof(no);
+    for (int r = 0; r < no; ++r) {
+      so[r] = ablk(O[r], 4);
+      dof[r] = oblk(r, 1, 0);
+    }
+    long long *dso = nullptr, *ddo = nullptr;
+    SWCHK(upload(h, &dso, so.data(), so.size()));
+    SWCHK(upload(h, &ddo, dof.data(), dof.size()));
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_block_inverse, dim3(no), dim3(256), 0, h->stream, Av, (const long long*)dso,
+                         lv.eo_op[2].bsr_vals, (const long long*)ddo, info);
+      KLAUNCH_CHECK();
+    }
+    SWCHK(stream_sync(h));
+    SWCHK(dev_free(h, dso));
+    SWCHK(dev_free(h, ddo));
+  }
+  auto products = [&](const std::vector<int>& ptr, const std::vector<long long>& ao,
+                      const std::vector<long long>& bo, const cplx* Ab, const cplx* Bb,
+                      const std::vector<long long>& io, double sign, cplx* out,
+                      const std::vector<long long>& oo) -> int {
+    int* dptr = nullptr;
+    long long *dao = nullptr, *dbo = nullptr, *dio = nullptr, *doo = nullptr;
+    SWCHK(upload(h, &dptr, ptr.data(), ptr.size()));
+    SWCHK(upload(h, &dao, ao.data(), ao.size()));
+    SWCHK(upload(h, &dbo, bo.data(), bo.size()));
+    SWCHK(upload(h, &dio, io.data(), io.size()));
+    SWCHK(upload(h, &doo, oo.data(), oo.size()));
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_block_products, dim3((unsigned)oo.size()), dim3(256), 0, h->stream,
+                         (const int*)dptr, (const long long*)dao, (const long long*)dbo, Ab, Bb,
+                         (const long long*)dio, Av, sign, out, (const long long*)doo);
+      KLAUNCH_CHECK();
+    }
+    SWCHK(stream_sync(h));
+    SWCHK(dev_free(h, dptr));
+    SWCHK(dev_free(h, dao));
+    SWCHK(dev_free(h, dbo));
+    SWCHK(dev_free(h, dio));
+    SWCHK(dev_free(h, doo));
+    return 0;
+  };
+  const cplx* Gv = lv.eo_op[2].bsr_vals;
+  // F(e, j) = A(e, j) G(o_j);  Hb(o, j) = G(o) A(o, j)
+  {
+    std::vector<int> ptr;
+    std::vector<long long> ao, bo, io, oo;
+    for (int r = 0; r < ne; ++r)
+      for (int j = 0; j < 4; ++j) {
+        ptr.push_back((int)ao.size());
+        ao.push_back(ablk(E[r], j));
+        bo.push_back(oblk(rank[nbr[(size_t)E[r] * 5 + j]], 1, 0));
+        io.push_back(-1);
+        oo.push_back(oblk(r, 4, j));
+      }
+    ptr.push_back((int)ao.size());
+    SWCHK(products(ptr, ao, bo, Av, Gv, io, 1.0, lv.eo_op[1].bsr_vals, oo));
+  }
+  {
+    std::vector<int> ptr;
+    std::vector<long long> ao, bo, io, oo;
+    for (int r = 0; r < no; ++r)
+      for (int j = 0; j < 4; ++j) {
+        ptr.push_back((int)ao.size());
+        ao.push_back(oblk(r, 1, 0));
+        bo.push_back(ablk(O[r], j));
+        io.push_back(-1);
+        oo.push_back(oblk(r, 4, j));
+      }
+    ptr.push_back((int)ao.size());
+    SWCHK(products(ptr, ao, bo, Gv, Av, io, 1.0, lv.eo_op[3].bsr_vals, oo));
+  }
+  // S(e, slot) = [slot == own] D(e) - sum over (j, j') with target(o_j, j') in that slot of F(e, j) A(o_j, j')
+  {
+    std::vector<int> ptr;
+    std::vector<long long> ao, bo, io, oo;
+    for (int r = 0; r < ne; ++r) {
+      std::vector<std::pair<long long, long long>> lists[9];
+      for (int j = 0; j < 4; ++j) {
+        const int o = nbr[(size_t)E[r] * 5 + j];
+        for (int jp = 0; jp < 4; ++jp) {
+          const int q = slot_of(E[r], nbr[(size_t)o * 5 + jp]);
+          if (q < 0) return sw_fail(h, "level %d: a two-hop target is outside the nine-point pattern", level);
+          lists[q].push_back({oblk(r, 4, j), ablk(o, jp)});
+        }
+      }
+      for (int q = 0; q < 9; ++q) {
+        ptr.push_back((int)ao.size());
+        for (auto& pr : lists[q]) {
+          ao.push_back(pr.first);
+          bo.push_back(pr.second);
+        }
+        io.push_back(q == 8 ? ablk(E[r], 4) : -1);
+        oo.push_back(oblk(r, 9, q));
+      }
+    }
+    ptr.push_back((int)ao.size());
+    SWCHK(products(ptr, ao, bo, lv.eo_op[1].bsr_vals, Av, io, -1.0, lv.eo_op[0].bsr_vals, oo));
+  }
+  int hinfo = 0;
+  HIPCHK(hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost));
+  SWCHK(dev_free(h, info));
+  if (hinfo != 0) return sw_fail(h, "level %d: a diagonal block of an odd site is singular", level);
+  return 0;
+}
+
+// Y = op X for one of a block level's even-odd operators (which: 0 S, 1 F, 2 G, 3 Hb) on full-length
+// level vectors in the reference layout; rows the operator does not write come back zero
+int sw_apply_eo_operator(sw_engine* h, int hid, int level, int which, int nb, const double* X, double* Y) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (which < 0 || which > 3 || nb <= 0 || !X || !Y) return sw_fail(h, "sw_apply_eo_operator: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[hid].lv[level];
+  if (lv.stencil || !lv.eo_op[which].set) return sw_fail(h, "level %d has no even-odd operator %d", level, which);
+  const int nbp = pad64(nb);
+  cplx *a, *b;
+  SWCHK(io_vectors(h, lv, nbp, &a, &b));
+  SWCHK(pack_host(h, lv, nb, X, a, nbp));
+  SWCHK(zero_vec(h, b, lv.n, nbp));
+  SWCHK(launch_bsr(h, lv.eo_op[which], 0, a, nullptr, b, nbp, T_MVM, cplx{0.0, 0.0}));
+  return unpack_host(h, lv, nb, b, Y, nbp);
+}
+
 int sw_get_level_bsr(sw_engine* h, int hid, int level, int* KS, int32_t* kcol, double* vals) {
   SWCHK(check_hier(h, hid, level, false));
   HIPCHK(hipSetDevice(h->device));

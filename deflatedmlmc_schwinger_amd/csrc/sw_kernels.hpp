@@ -1103,6 +1103,105 @@ __global__ __launch_bounds__(SW_BLOCK) void k_cast(const CI* __restrict__ src, C
 }
 
 // ------------------------------------------------------------------------------------------
+// Device-side construction of a block level's even-odd operators (sw_setup_eo_operators):
+//   G = D_oo^-1,  F = A_eo G,  Hb = G A_oe,  S = D_ee - F A_oe
+// as batched 16 x 16 complex algebra on site blocks in the kernels' own packed form: a block is four
+// k-step tiles of 64 = 256 values, element (i, c) at [(c >> 2) * 64 + i + 16 * (c & 3)].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int blk_pos_row(int q) { return q & 15; }                       // packed position -> row
+__device__ __forceinline__ int blk_pos_col(int q) { return 4 * (q >> 6) + ((q & 63) >> 4); }   // -> column
+
+// inv[b] = src[b]^-1 (Gauss-Jordan with partial pivoting), one workgroup of 256 threads per block;
+// soff / doff: element offsets of the source and destination blocks; info[0] |= 1 on a zero pivot
+__global__ __launch_bounds__(256) void k_block_inverse(const cplx* __restrict__ src,
+                                                       const long long* __restrict__ soff,
+                                                       cplx* __restrict__ dst,
+                                                       const long long* __restrict__ doff,
+                                                       int* __restrict__ info) {
+  __shared__ cplx a[16][33];       // [A | I], padded
+  __shared__ cplx fac[16];
+  __shared__ int piv;
+  const int q = threadIdx.x;
+  const int i = blk_pos_row(q), c = blk_pos_col(q);
+  const cplx* s = src + soff[blockIdx.x];
+  a[i][c] = s[q];
+  a[i][16 + c] = cmake(i == c ? 1.0 : 0.0, 0.0);
+  __syncthreads();
+  for (int k = 0; k < 16; ++k) {
+    if (q == 0) {
+      int p = k;
+      double best = a[k][k].x * a[k][k].x + a[k][k].y * a[k][k].y;
+      for (int r = k + 1; r < 16; ++r) {
+        const double m = a[r][k].x * a[r][k].x + a[r][k].y * a[r][k].y;
+        if (m > best) {
+          best = m;
+          p = r;
+        }
+      }
+      piv = p;
+      if (best == 0.0) atomicOr(info, 1);
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k && q < 32) {
+      const cplx t = a[k][q];
+      a[k][q] = a[p][q];
+      a[p][q] = t;
+    }
+    __syncthreads();
+    if (q < 16) fac[q] = a[q][k];             // column k before it is eliminated
+    __syncthreads();
+    const cplx pv = fac[k];
+    const double d = pv.x * pv.x + pv.y * pv.y;
+    const cplx ip = d > 0.0 ? cmake(pv.x / d, -pv.y / d) : cmake(0.0, 0.0);
+    if (q < 32) a[k][q] = cmul(a[k][q], ip);
+    __syncthreads();
+    // rows r != k: a[r][:] -= fac[r] * a[k][:]   (512 entries, two per thread)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = q + 256 * e;
+      const int r = idx >> 5, cc = idx & 31;
+      if (r != k) {
+        const cplx f = fac[r];
+        const cplx t = cmul(f, a[k][cc]);
+        a[r][cc] = csub(a[r][cc], t);
+      }
+    }
+    __syncthreads();
+  }
+  dst[doff[blockIdx.x] + q] = a[i][16 + c];
+}
+
+// out[b] = (ioff[b] >= 0 ? init[ioff[b]] : 0) + sign * sum_{t in [ptr[b], ptr[b+1])} A[aoff[t]] B[boff[t]]
+// (16 x 16 complex products of packed blocks), one workgroup of 256 threads per output block
+__global__ __launch_bounds__(256) void k_block_products(const int* __restrict__ ptr,
+                                                        const long long* __restrict__ aoff,
+                                                        const long long* __restrict__ boff,
+                                                        const cplx* __restrict__ A,
+                                                        const cplx* __restrict__ B,
+                                                        const long long* __restrict__ ioff,
+                                                        const cplx* __restrict__ init, double sign,
+                                                        cplx* __restrict__ out,
+                                                        const long long* __restrict__ ooff) {
+  __shared__ cplx as[16][17], bs[16][17];
+  const int q = threadIdx.x;
+  const int i = blk_pos_row(q), c = blk_pos_col(q);
+  const int b = blockIdx.x;
+  cplx acc = cmake(0.0, 0.0);
+  for (int t = ptr[b]; t < ptr[b + 1]; ++t) {
+    as[i][c] = A[aoff[t] + q];
+    bs[i][c] = B[boff[t] + q];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) cfma(acc, as[i][m], bs[m][c]);
+    __syncthreads();
+  }
+  cplx o = cmake(sign * acc.x, sign * acc.y);
+  if (ioff[b] >= 0) o = cadd(o, init[ioff[b] + q]);
+  out[ooff[b] + q] = o;
+}
+
+// ------------------------------------------------------------------------------------------
 // Pack / unpack between the reference's host layout ([probe][natural index], probe-major) and
 // the engine layout ([internal row][probe]).  rowmap[natural] = internal row (NULL: identity).
 // ------------------------------------------------------------------------------------------

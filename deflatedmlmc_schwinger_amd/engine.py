@@ -69,6 +69,8 @@ def load_library():
     sig("sw_set_gmres_smoother", i32, vp, i32, i32, i32, i32)
     sig("sw_set_eo_smoother", i32, vp, i32, i32, i32, vp)
     sig("sw_set_eo_operator", i32, vp, i32, i32, i32, i32, i32, vp, vp, vp)
+    sig("sw_setup_eo_operators", i32, vp, i32, i32, i32)
+    sig("sw_apply_eo_operator", i32, vp, i32, i32, i32, i32, vp, vp)
     sig("sw_get_level_bsr", i32, vp, i32, i32, P(i32), vp, vp)
     sig("sw_setup_testvectors", i32, vp, i32, i32, i32, C.c_uint64, i32, dbl, i32, i32, vp)
     sig("sw_setup_transfer", i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp)
@@ -128,7 +130,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "sw_create", "sw_destroy", "sw_last_error", "sw_device_count", "sw_version", "sw_hier_begin",
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
-    "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator",
+    "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator", "sw_setup_eo_operators", "sw_apply_eo_operator",
     "sw_get_level_bsr", "sw_setup_testvectors", "sw_setup_transfer",
     "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
@@ -257,6 +259,17 @@ class Engine:
             raise EngineError("even-odd operator arrays have inconsistent shapes")
         self._chk(self._lib.sw_set_eo_operator(self._h, hid, level, int(which), RT, KS, _ptr(tmap),
                                                _ptr(kcol), _ptr(vals)), "sw_set_eo_operator")
+
+    def setup_eo_operators(self, hid, level, Lc):
+        """S, F, G, Hb of block level `level` (Lc x Lc sites) built on the device from its operator."""
+        self._chk(self._lib.sw_setup_eo_operators(self._h, hid, level, int(Lc)), "sw_setup_eo_operators")
+
+    def apply_eo_operator(self, hid, level, which, X):
+        X2, single = self._io(X, self._n(hid, level))
+        Y = np.empty_like(X2)
+        self._chk(self._lib.sw_apply_eo_operator(self._h, hid, level, int(which), X2.shape[0], _ptr(X2),
+                                                 _ptr(Y)), "sw_apply_eo_operator")
+        return Y[0] if single else Y
 
     def level_bsr(self, hid, level):
         """A (device-built) level operator in MFMA block-row form: (kcol[RT, KS], vals[RT, KS, 64])."""

@@ -187,6 +187,23 @@ class _EngineSchur:
         return self.D * np.asarray(v) - w[self.E]
 
 
+class _EngineBlockSchur:
+    """S = D_ee - A_eo D_oo^-1 A_oe of a block level as the engine holds it (sw_setup_eo_operators),
+    acting on the even sites' rows, through sw_apply_eo_operator (for hierarchy.smoother_weights)."""
+
+    def __init__(self, eng, hid, level, Lc):
+        site = np.arange(Lc * Lc)
+        even = (((site % Lc) + (site // Lc)) & 1) == 0
+        self.E = np.nonzero(np.repeat(even, 16))[0]
+        self.eng, self.hid, self.level, self.n = eng, hid, level, Lc * Lc * 16
+        self.shape = (self.E.size, self.E.size)
+
+    def __matmul__(self, v):
+        u = np.zeros(self.n, dtype=np.complex128)
+        u[self.E] = v
+        return self.eng.apply_eo_operator(self.hid, self.level, 0, u)[self.E]
+
+
 def device_solver_hierarchy(eng, lat, cfg, hid):
     """The solver hierarchy built ON THE GPU (solver_cfg["setup"] = "device"): test vectors by
     batched inverse iteration (first unpreconditioned on each new level, then one refinement pass
@@ -269,10 +286,17 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                         eng.set_eo_smoother(hid, 0, _hier.smoother_weights(
                             _EngineSchur(eng, hid, L, mass), cyc[1]))
                     elif lv in eo_levels:
-                        # block level: its operator comes back in block-row form, the four even-odd
-                        # operators are formed on the host (batched 16 x 16 algebra) and uploaded
-                        _hier.upload_coarse_eo([eng], hid, lv, eng.level_bsr(hid, lv), geo[lv - 1]["Lc"],
-                                               cyc[1])
+                        Lc_l = geo[lv - 1]["Lc"]
+                        if Lc_l >= 8 and cfg.get("setup_eo", "device") == "device":
+                            # block level: S, F, G, Hb by batched 16 x 16 algebra on the device, the
+                            # polynomial fitted to S through the engine
+                            eng.setup_eo_operators(hid, lv, Lc_l)
+                            eng.set_eo_smoother(hid, lv, _hier.smoother_weights(
+                                _EngineBlockSchur(eng, hid, lv, Lc_l), cyc[1]))
+                        else:
+                            # tiny lattices: the operator comes back in block-row form, the four
+                            # operators are formed on the host and uploaded
+                            _hier.upload_coarse_eo([eng], hid, lv, eng.level_bsr(hid, lv), Lc_l, cyc[1])
 
     eng.hier_begin(hid, nl)
     eng.set_lattice(hid, L, mass, U1, U2)

@@ -88,6 +88,14 @@ int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const doubl
 int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int KS, const int32_t* tmap,
                        const int32_t* kcol, const double* vals);
 int sw_get_level_bsr(sw_engine* h, int hid, int level, int* KS, int32_t* kcol, double* vals);
+/* The same four operators built ON THE DEVICE from the level's own block-row operator (as
+ * sw_setup_galerkin leaves it: five site blocks per row, own site last; Lc x Lc sites, Lc even and >= 8):
+ * batched 16x16 inverses of the odd sites' diagonal blocks and block products, no host algebra.
+ * sw_apply_eo_operator applies one of them (which as above) to nb full-length level vectors in the
+ * reference layout (rows it does not write come back zero) -- used to fit the smoother polynomial to S
+ * and by the parity tests.  Build-only extension of the even-odd smoother above. */
+int sw_setup_eo_operators(sw_engine* h, int hid, int level, int Lc);
+int sw_apply_eo_operator(sw_engine* h, int hid, int level, int which, int nb, const double* X, double* Y);
 /* Reference-faithful cycle at `level` ("function_iters / total_complexity in both
  * modes"): MG.one_mg_step exactly as multigrid.py:369-447 lays it out -- smooth, residual,
  * restrict, recurse, prolong, residual, smooth -- with `cycles` restart cycles of unpreconditioned

@@ -2196,38 +2196,6 @@ int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* n
   return 0;
 }
 
-// rocSOLVER (LU with partial pivoting, the device counterpart of np.linalg.inv at
-// multigrid.py:342-344), loaded on first use so that the library has no hard dependency on it
-namespace {
-struct RocSolver {
-  void* lib_blas = nullptr;
-  void* lib_solver = nullptr;
-  int (*create)(void**) = nullptr;
-  int (*destroy)(void*) = nullptr;
-  int (*set_stream)(void*, hipStream_t) = nullptr;
-  int (*zgetrf)(void*, int, int, void*, int, int*, int*) = nullptr;
-  int (*zgetri)(void*, int, void*, int, int*, int*) = nullptr;
-  bool tried = false, ok = false;
-};
-RocSolver g_rs;
-bool load_rocsolver() {
-  if (g_rs.tried) return g_rs.ok;
-  g_rs.tried = true;
-  g_rs.lib_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!g_rs.lib_blas) g_rs.lib_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-  g_rs.lib_solver = dlopen("librocsolver.so", RTLD_NOW);
-  if (!g_rs.lib_solver) g_rs.lib_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW);
-  if (!g_rs.lib_blas || !g_rs.lib_solver) return false;
-  g_rs.create = (int (*)(void**))dlsym(g_rs.lib_blas, "rocblas_create_handle");
-  g_rs.destroy = (int (*)(void*))dlsym(g_rs.lib_blas, "rocblas_destroy_handle");
-  g_rs.set_stream = (int (*)(void*, hipStream_t))dlsym(g_rs.lib_blas, "rocblas_set_stream");
-  g_rs.zgetrf = (int (*)(void*, int, int, void*, int, int*, int*))dlsym(g_rs.lib_solver, "rocsolver_zgetrf");
-  g_rs.zgetri = (int (*)(void*, int, void*, int, int*, int*))dlsym(g_rs.lib_solver, "rocsolver_zgetri");
-  g_rs.ok = g_rs.create && g_rs.destroy && g_rs.set_stream && g_rs.zgetrf && g_rs.zgetri;
-  return g_rs.ok;
-}
-}  // namespace
-
 int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   SWCHK(check_hier(h, hid, 0, false));
   HIPCHK(hipSetDevice(h->device));
@@ -2238,12 +2206,18 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   if (H.nlevels < 2 || !A.set || A.bsr_KS <= 0) return sw_fail(h, "coarsest level has no block-row operator");
   const int n = lv.n;
   if (n % 16) return sw_fail(h, "coarsest size %d is not a multiple of 16", n);
-  if (!load_rocsolver()) return sw_fail(h, "rocSOLVER / rocBLAS could not be loaded (%s)", dlerror());
+  if (n > 8192) return sw_fail(h, "coarsest size %d too large for the in-engine dense inverse", n);
   cplx* D = nullptr;
-  int* ipiv = nullptr;
+  cplx* colk = nullptr;
+  cplx* pvinv = nullptr;
+  int* pivs = nullptr;
   SWCHK(dev_realloc(h, &D, (size_t)n * n));
-  SWCHK(dev_realloc(h, &ipiv, (size_t)n + 1));
+  SWCHK(dev_realloc(h, &colk, (size_t)n));
+  SWCHK(dev_realloc(h, &pvinv, (size_t)1));
+  SWCHK(dev_realloc(h, &pivs, (size_t)n + 1));
+  int* info = pivs + n;
   HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
+  HIPCHK(hipMemsetAsync(info, 0, sizeof(int), h->stream));
   {
     LaunchScope ls(h, T_OTHER);
     const int items = (n / 16) * A.bsr_KS;
@@ -2252,32 +2226,33 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
                        n / 16, A.bsr_KS, n, D);
     KLAUNCH_CHECK();
   }
-  // the row-major buffer read column-major is D^T; (D^T)^-1 = (D^-1)^T, i.e. D^-1 row-major again
-  void* rb = nullptr;
-  SWCHK(stream_sync(h));
-  (void)hipGetLastError();          // rocBLAS must not inherit a stale status
-  int crc = g_rs.create(&rb);
-  if (crc != 0 || !rb) {            // seen once under pytest (status 6), not reproducible alone: retry
-    (void)hipDeviceSynchronize();
-    (void)hipGetLastError();
-    rb = nullptr;
-    crc = g_rs.create(&rb);
+  // Gauss-Jordan with partial pivoting, in place (the device counterpart of np.linalg.inv at
+  // multigrid.py:342-344); hand-written, no library handle involved
+  {
+    const dim3 g1((n + SW_BLOCK - 1) / SW_BLOCK);
+    const dim3 gu((n + 63) / 64, (n + 16 * SW_WAVES_PER_BLOCK - 1) / (16 * SW_WAVES_PER_BLOCK));
+    for (int k = 0; k < n; ++k) {
+      hipLaunchKernelGGL(swk::k_gj_pivot, dim3(1), dim3(1024), 0, h->stream, (const cplx*)D, n, k, pivs,
+                         pvinv, info);
+      hipLaunchKernelGGL(swk::k_gj_swap_rows, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k, (const int*)pivs);
+      hipLaunchKernelGGL(swk::k_gj_column_and_scale, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k,
+                         (const cplx*)pvinv, colk);
+      hipLaunchKernelGGL(swk::k_gj_update, gu, dim3(SW_BLOCK), 0, h->stream, D, n, k, (const cplx*)colk);
+    }
+    hipLaunchKernelGGL(swk::k_gj_unpermute, g1, dim3(SW_BLOCK), 0, h->stream, D, n, (const int*)pivs);
+    KLAUNCH_CHECK();
+    h->launches += 4 * (long long)n + 1;
   }
-  if (crc != 0 || !rb) {
-    (void)dev_free(h, D);
-    (void)dev_free(h, ipiv);
-    return sw_fail(h, "rocblas_create_handle failed (rocblas_status %d)", crc);
-  }
-  int rc = g_rs.set_stream(rb, h->stream);
-  int* info = ipiv + n;
-  if (rc == 0) rc = g_rs.zgetrf(rb, n, n, D, n, ipiv, info);
-  if (rc == 0) rc = g_rs.zgetri(rb, n, D, n, ipiv, info);
-  hipError_t se = hipStreamSynchronize(h->stream);
   int hinfo = 0;
-  if (se == hipSuccess) se = hipMemcpy(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost);
-  g_rs.destroy(rb);
-  if (rc != 0 || se != hipSuccess) return sw_fail(h, "rocSOLVER zgetrf/zgetri failed (status %d)", rc);
-  if (hinfo != 0) return sw_fail(h, "coarsest operator is singular (pivot %d)", hinfo);
+  HIPCHK(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  SWCHK(stream_sync(h));
+  if (hinfo != 0) {
+    (void)dev_free(h, D);
+    (void)dev_free(h, colk);
+    (void)dev_free(h, pvinv);
+    (void)dev_free(h, pivs);
+    return sw_fail(h, "coarsest operator is singular");
+  }
   SWCHK(free_op(h, H.cinv));
   EllOp& op = H.cinv;
   op.nrows = op.ncols = n;
@@ -2295,7 +2270,9 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   op.set = true;
   SWCHK(stream_sync(h));
   SWCHK(dev_free(h, D));
-  SWCHK(dev_free(h, ipiv));
+  SWCHK(dev_free(h, colk));
+  SWCHK(dev_free(h, pvinv));
+  SWCHK(dev_free(h, pivs));
   return 0;
 }
 

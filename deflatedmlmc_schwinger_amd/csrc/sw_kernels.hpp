@@ -1202,6 +1202,108 @@ __global__ __launch_bounds__(256) void k_block_products(const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// In-place dense inverse of the coarsest operator (sw_setup_invert_coarsest): Gauss-Jordan with
+// partial pivoting on the row-major [n][n] matrix, four small launches per pivot step (n <= 8192:
+// the whole inverse is n^3 complex updates = 0.2 s of HBM traffic at n = 4096, 3 ms at n = 1024).
+//   step k:  p = argmax_{r >= k} |a[r][k]| ;  rows k <-> p ;  c_r = a[r][k], column k := e_k ;
+//            row k *= 1 / pivot ;  a[r][:] -= c_r a[k][:]  (r != k) ;   afterwards the row swaps are
+//   undone on the columns in reverse order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_gj_pivot(const cplx* __restrict__ A, int n, int k,
+                                                   int* __restrict__ pivs, cplx* __restrict__ pvinv,
+                                                   int* __restrict__ info) {
+  __shared__ double bm[1024];
+  __shared__ int bi[1024];
+  const int t = threadIdx.x;
+  double best = -1.0;
+  int arg = k;
+  for (int r = k + t; r < n; r += 1024) {
+    const cplx v = A[(size_t)r * n + k];
+    const double m = v.x * v.x + v.y * v.y;
+    if (m > best) {
+      best = m;
+      arg = r;
+    }
+  }
+  bm[t] = best;
+  bi[t] = arg;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (t < s && (bm[t + s] > bm[t] || (bm[t + s] == bm[t] && bi[t + s] < bi[t]))) {
+      bm[t] = bm[t + s];
+      bi[t] = bi[t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const int p = bi[0];
+    pivs[k] = p;
+    const cplx v = A[(size_t)p * n + k];
+    const double d = v.x * v.x + v.y * v.y;
+    if (d > 0.0) {
+      *pvinv = cmake(v.x / d, -v.y / d);
+    } else {
+      *pvinv = cmake(0.0, 0.0);
+      atomicOr(info, 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_swap_rows(cplx* __restrict__ A, int n, int k,
+                                                           const int* __restrict__ pivs) {
+  const int c = blockIdx.x * SW_BLOCK + threadIdx.x;
+  const int p = pivs[k];
+  if (c >= n || p == k) return;
+  const cplx t = A[(size_t)k * n + c];
+  A[(size_t)k * n + c] = A[(size_t)p * n + c];
+  A[(size_t)p * n + c] = t;
+}
+
+// thread t: as a row, colk[t] = a[t][k] and a[t][k] := (t == k); then, as a column, a[k][t] *= 1/pivot
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_column_and_scale(cplx* __restrict__ A, int n, int k,
+                                                                  const cplx* __restrict__ pvinv,
+                                                                  cplx* __restrict__ colk) {
+  const int t = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  colk[t] = A[(size_t)t * n + k];
+  A[(size_t)t * n + k] = cmake(t == k ? 1.0 : 0.0, 0.0);
+  A[(size_t)k * n + t] = cmul(A[(size_t)k * n + t], *pvinv);
+}
+
+// a[r][c] -= colk[r] * a[k][c] for r != k; one wave per row segment of 64 columns
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_update(cplx* __restrict__ A, int n, int k,
+                                                        const cplx* __restrict__ colk) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int r0 = (blockIdx.y * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
+  if (c >= n) return;
+  const cplx rk = A[(size_t)k * n + c];
+#pragma unroll 4
+  for (int r = r0; r < r0 + 16 && r < n; ++r) {
+    if (r == k) continue;
+    cplx v = A[(size_t)r * n + c];
+    const cplx f = colk[r];
+    cfma(v, cmake(-f.x, -f.y), rk);
+    A[(size_t)r * n + c] = v;
+  }
+}
+
+// undo the row swaps on the columns, last swap first; one thread per row
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_unpermute(cplx* __restrict__ A, int n,
+                                                           const int* __restrict__ pivs) {
+  const int r = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  cplx* row = A + (size_t)r * n;
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = pivs[k];
+    if (p != k) {
+      const cplx t = row[k];
+      row[k] = row[p];
+      row[p] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Pack / unpack between the reference's host layout ([probe][natural index], probe-major) and
 // the engine layout ([internal row][probe]).  rowmap[natural] = internal row (NULL: identity).
 // ------------------------------------------------------------------------------------------

@@ -261,11 +261,11 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
             done = False
             if cfg.get("setup_inverse", "device") == "device":
                 try:
-                    eng.setup_invert_coarsest(hid)             # rocSOLVER LU on the GPU
+                    eng.setup_invert_coarsest(hid)             # Gauss-Jordan on the GPU (k_gj_*)
                     done = True
                 except _engine.EngineError as err:
-                    # rocSOLVER / rocBLAS unavailable or refusing a handle: the same LU inverse on
-                    # the host (setup only, never the solve path)
+                    # refused (size, singular pivot): LAPACK on the host decides (setup only, never
+                    # the solve path)
                     sys.stderr.write("setup_gpu: %s -- inverting the coarsest operator on the host\n" % err)
             if not done:
                 eng.set_coarsest_inv(hid, _hier.dense_inverse(eng.level_dense(hid, nl - 1)))

@@ -130,9 +130,9 @@ int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, co
                       int G, int K, const int32_t* pcols, const int64_t* pmap, const int32_t* porder);
 int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* nbr);
 int sw_get_level_dense(sw_engine* h, int hid, int level, double* dense);
-/* Dense inverse of a device-built coarsest operator without leaving the GPU: rocSOLVER LU
- * (zgetrf + zgetri, loaded on first use) on the stream of the engine, result packed into the MFMA
- * block-row form sw_set_coarsest_inv would upload (np.linalg.inv at multigrid.py:342-344). */
+/* Dense inverse of a device-built coarsest operator without leaving the GPU: in-place Gauss-Jordan
+ * with partial pivoting by the engine's own kernels (k_gj_*; n <= 8192), then packed into MFMA block-row
+ * form as sw_set_coarsest_inv would (multigrid.py:342-344: np.linalg.inv).  Fails on a singular operator. */
 int sw_setup_invert_coarsest(sw_engine* h, int hid);
 /* Mark the hierarchy complete (allocates level workspaces lazily). */
 int sw_hier_end(sw_engine* h, int hid);

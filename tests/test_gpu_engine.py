@@ -999,7 +999,7 @@ def test_even_odd_operators_built_on_the_device_match_the_host_construction():
     mg = MG(A)
     mg.setup_solver_only(cfg)
     eng = mg.engine
-    assert mg.solver_info["levels"] == [2 * L * L, L * L // 2, L * L // 8, L * L // 32]
+    assert mg.solver_info["levels"] == [2 * L * L, L * L, L * L // 4, L * L // 16]
     for level, Lc in ((1, 32), (2, 16)):
         nbr, blk = hierarchy.site_blocks_from_block_rows(*eng.level_bsr(SOLVER_HID, level))
         ops = hierarchy.coarse_schur_blocks(nbr, blk, Lc)

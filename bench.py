@@ -152,19 +152,20 @@ def run(args):
         Ls = args.lattice
         U1s, U2s = matrix.synthetic_links(Ls, 0.204, 2024)
         # 4x4 site aggregates once, then 2x2 until the coarsest level is 16 x 16 sites (4096 rows);
-        # level 0 smoothed on its even-odd Schur complement, a 2-step K-cycle around the solves of
-        # levels 2 and 3, plain V-cycle below (profiles/r02_cfg_sweeps.txt: 165 probe-samples/s at
-        # 1024^2 against 91 for the three-level 4x4 hierarchy with K-cycles everywhere)
+        # every level smoothed on its even-odd Schur complement (operators built on the device), a
+        # 2-step K-cycle around the solves of levels 1 and 2, plain V-cycle below
+        # (profiles/r02_synthetic_lattices.txt: 267 probe-samples/s at 1024^2, 8 iterations; 218 with
+        # only level 0 even-odd; 91 for the three-level 4x4 hierarchy with K-cycles everywhere)
         depth = [[4, 8]]
         Lc = Ls // 4
         while Lc > 16 and Lc % 8 == 0:
             depth.append([2, 8])
             Lc //= 2
         nsm = len(depth)
-        cyc = [[0, 6, 0]] + [[0, 7, 2 if (i == 1 or (i == 2 and nsm >= 5)) and i < nsm - 1 else 0]
+        cyc = [[0, 8, 0]] + [[0, 5, 2 if (i == 1 or (i == 2 and nsm >= 5)) and i < nsm - 1 else 0]
                              for i in range(1, nsm)]
-        cyc[-1] = [0, 16, 0] if nsm > 1 else cyc[-1]
-        scfg = {"coarsening": depth, "cycle": cyc, "restart": 3, "eo_levels": [0],
+        cyc[-1] = [0, 14, 0] if nsm > 1 else cyc[-1]
+        scfg = {"coarsening": depth, "cycle": cyc, "restart": 3, "eo_levels": list(range(nsm)),
                 "setup": os.environ.get("SW_SYNTH_SETUP", "device"),
                 "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1}
         if args.cfg:

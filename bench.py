@@ -151,19 +151,20 @@ def run(args):
         # BASELINE config 5: sigma = 0.204 <-> mean plaquette ~0.92, m = -0.05
         Ls = args.lattice
         U1s, U2s = matrix.synthetic_links(Ls, 0.204, 2024)
-        # 4x4 site aggregates once, then 2x2 until the coarsest level is 16 x 16 sites (4096 rows);
+        # 8x8 site aggregates once, then 2x2 until the coarsest level is 16 x 16 sites (4096 rows);
         # every level smoothed on its even-odd Schur complement (operators built on the device), a
-        # 2-step K-cycle around the solves of levels 1 and 2, plain V-cycle below
-        # (profiles/r02_synthetic_lattices.txt: 267 probe-samples/s at 1024^2, 8 iterations; 218 with
-        # only level 0 even-odd; 91 for the three-level 4x4 hierarchy with K-cycles everywhere)
-        depth = [[4, 8]]
-        Lc = Ls // 4
+        # 2-step K-cycle around the solve of level 1, plain V-cycle below
+        # (profiles/r02_synthetic_lattices.txt, 1024^2: 325 probe-samples/s, 8 iterations; 264 with 4x4
+        # aggregates first; 218 with only level 0 even-odd; 91 for round 2's first three-level hierarchy)
+        a0 = 8 if Ls % 8 == 0 and Ls // 8 >= 16 else 4
+        depth = [[a0, 8]]
+        Lc = Ls // a0
         while Lc > 16 and Lc % 8 == 0:
             depth.append([2, 8])
             Lc //= 2
         nsm = len(depth)
-        cyc = [[0, 8, 0]] + [[0, 5, 2 if (i == 1 or (i == 2 and nsm >= 5)) and i < nsm - 1 else 0]
-                             for i in range(1, nsm)]
+        cyc = [[0, 14, 0]] + [[0, 10 if i == 1 else 8, 2 if i == 1 and i < nsm - 1 else 0]
+                              for i in range(1, nsm)]
         cyc[-1] = [0, 14, 0] if nsm > 1 else cyc[-1]
         scfg = {"coarsening": depth, "cycle": cyc, "restart": 3, "eo_levels": list(range(nsm)),
                 "setup": os.environ.get("SW_SYNTH_SETUP", "device"),

@@ -571,16 +571,19 @@ DEFAULT_SOLVER_CFG = {
 }
 
 
-# The benchmark's hierarchy for schwinger128 (bench.py; any L with L/16 a multiple of 4): one more
-# coarsening than the default, so the dense inverse shrinks from 4096^2 to 1024^2 and the 4096-row
-# level is smoothed instead; built entirely on the GPU (setup_gpu.py).
-# 128^2, one MI355X (3 streams): 18k probe-samples/s, 10 outer iterations with every level smoothed
-# even-odd (12.2k with level 0 only, 9.9k / 14 iterations without; 8.8k for DEFAULT_SOLVER_CFG).
+# The benchmark's hierarchy for schwinger128 (bench.py; any L with L/8 a multiple of 4), built entirely
+# on the GPU (setup_gpu.py, 0.4 s): 8 x 8 site aggregates straight to a 4096-row level (16 x 16 sites x
+# 16), then 2 x 2 to a 1024^2 dense inverse; both smoothed levels on their even-odd Schur complements.
+# One MI355X, 3 streams, 10 outer iterations: 20.8k probe-samples/s (30k+ with precond_precision f32).
+# History of the shape: 8.8k for DEFAULT_SOLVER_CFG (4096^2 dense inverse) -> 9.9k with a 16384-row
+# level in between (4 x 4 aggregates first) -> 12.2k level 0 even-odd -> 16.7-18.1k every level
+# even-odd -> 20.8k without the 16384-row level: with twelve Schur steps on the lattice level the
+# coarser first coarse space is enough, and the level whose 16 x 16 blocks made up 20 % of the time is gone.
 TUNED_SOLVER_CFG_128 = {
-    "coarsening": [(4, 8), (2, 8), (2, 8)],
-    "cycle": [(0, 8, 0), (0, 5, 0), (0, 14, 0)],
+    "coarsening": [(8, 8), (2, 8)],
+    "cycle": [(0, 12, 0), (0, 10, 0)],
     "smoother": "richardson",
-    "eo_levels": [0, 1, 2],     # levels smoothed on their even-odd Schur complement (half vectors)
+    "eo_levels": [0, 1],        # levels smoothed on their even-odd Schur complement (half vectors)
     "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count
     "setup": "device",
     "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,

@@ -995,7 +995,8 @@ def test_even_odd_operators_built_on_the_device_match_the_host_construction():
     from deflatedmlmc_schwinger_amd import hierarchy
     L = 128
     A = matrix.synthetic_matrix(L, -0.02, sigma=0.3, seed=77)
-    cfg = dict(hierarchy.TUNED_SOLVER_CFG_128, cycle=[(0, 4, 0), (0, 3, 0), (0, 5, 0)])
+    cfg = dict(hierarchy.TUNED_SOLVER_CFG_128, coarsening=[(4, 8), (2, 8), (2, 8)],
+               cycle=[(0, 4, 0), (0, 3, 0), (0, 5, 0)], eo_levels=[0, 1, 2])
     mg = MG(A)
     mg.setup_solver_only(cfg)
     eng = mg.engine

@@ -80,6 +80,11 @@ def main(out, extra=""):
                     summary[tag] = {"hbm_bytes_per_launch": (fmb + wmb) * 1e6,
                                     "fetch_bytes_per_launch_corrected": fmb * 1e6,
                                     "write_bytes_per_launch": wmb * 1e6}
+    # hierarchies whose first block level is small run it on the NT = 2 variant: bench.py calls the
+    # first block level "level-1 operator" whatever its size
+    l1, l2 = "k_bsr_mfma(level-1 operator)", "k_bsr_mfma(level-2 operator)"
+    if l1 not in summary and l2 in summary:
+        summary[l1] = summary.pop(l2)
     text = "\n".join(lines)
     open(os.path.join(out, "summary.txt"), "w").write(text + "\n")
     if summary:

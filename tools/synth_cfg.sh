@@ -3,7 +3,8 @@
 # "eo_levels|cycle" pairs, e.g. "[0]|[[0,6,0],[0,7,2],[0,7,2],[0,7,0],[0,16,0]]"; SYN_OPTS engine options.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 L=${SYN_L:-1024}
-depth='[[4,8]'; Lc=$((L/4)); while [ $Lc -gt 16 ]; do depth="$depth,[2,8]"; Lc=$((Lc/2)); done; depth="$depth]"
+A0=${SYN_AGG0:-4}     # edge of the level-0 aggregates, in sites
+depth="[[$A0,8]"; Lc=$((L/A0)); while [ $Lc -gt 16 ]; do depth="$depth,[2,8]"; Lc=$((Lc/2)); done; depth="$depth]"
 IFS=';' read -ra CF <<< "$SYN_CFGS"
 for c in "${CF[@]}"; do
   eo="${c%%|*}"; cyc="${c##*|}"

@@ -397,6 +397,15 @@ def coarse_schur_operators(A, Lc):
             "E_rows": E_rows, "O_rows": O_rows}
 
 
+def auto_solver_cfg(L):
+    """The solver configuration used when the caller names none: the tuned, device-built hierarchy where
+    the lattice allows it (8 x 8 aggregates, then 2 x 2, the last smoothed level at least 8 x 8 sites:
+    L a multiple of 16 and >= 128), the general default otherwise."""
+    if L % 16 == 0 and L // 16 >= 8:
+        return dict(TUNED_SOLVER_CFG_128)
+    return dict(DEFAULT_SOLVER_CFG)
+
+
 def eo_levels_of(cfg):
     """Levels smoothed on their even-odd Schur complement: cfg["eo_levels"], or [0] for the older
     switch cfg["eo_smoother"] = True."""

@@ -178,6 +178,8 @@ class MG:
                 eng.set_rhsmap(i, Cmat)
         # level-0 preconditioner
         cfg = params.get("solver_cfg") if params else None
+        if (cfg is None or cfg == "auto") and lat is not None:
+            cfg = _hier.auto_solver_cfg(lat[0])      # tuned, device-built where the lattice allows it
         want = True if params is None else params.get("use_solver_hierarchy", True)
         self._have_solver_hier = False
         if want and lat is not None:

@@ -38,6 +38,10 @@ class Problem:
         self.tp = utils.trace_params_from_params(params, "mlmc")
         self.tp['nr_deflat_vctrs'] = k_defl
         self.tp['mlmc_deflat_vctrs'] = [0] * 3
+        # the building-block tests below compare against the host-built default hierarchy; the
+        # drop-in flows (gateway presets, no solver_cfg) get hierarchy.auto_solver_cfg
+        from deflatedmlmc_schwinger_amd import hierarchy as _h
+        self.tp['solver_cfg'] = dict(_h.DEFAULT_SOLVER_CFG) if batch_solver_cfg is None else batch_solver_cfg
         self.mg = MG(self.A)
         self.mg.setup(dof=self.tp['dof'], aggrs=self.tp['aggrs'],
                       max_levels=self.tp['max_nr_levels'], dim=2,

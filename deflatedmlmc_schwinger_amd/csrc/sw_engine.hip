@@ -199,6 +199,11 @@ struct sw_engine {
   // second Gram-Schmidt pass in the short inner Krylov cycles (K-cycle, GMRES smoother): they are
   // preconditioners of 2-30 steps whose result feeds a flexible outer iteration, one pass suffices
   bool inner_cgs2 = false;
+  // last Arnoldi step of every restart cycle without its orthogonalisation pass: h_{j+1,j} from
+  // |A z|^2 - sum |h_{k,j}|^2 (single-pass Gram-Schmidt only; see fgmres)
+  bool pyth_last = true;
+  // even-odd smoothing of the stencil level on this many 64-probe chunks at a time (0: all at once)
+  int eo_chunk = 0;
   // single-precision preconditioner: every application of a multigrid cycle as the preconditioner of
   // an fp64 flexible GMRES (and sw_vcycle) runs in complex64 on the f32 matrix cores -- operands cast
   // at the boundary, residuals / orthogonalisation / verification stay fp64
@@ -1084,32 +1089,45 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
   if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
   a.w = cplx{0.0, 0.0};
   const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
   const double di = 1.0 / a.diag;
   cplx* bp = lv.r;   // b'_e lives in the even half of the level's residual buffer
-  {
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0, di,
-                       bpc);
-    KLAUNCH_CHECK();
+  // Probe chunks are independent and the whole sequence (hop, nu steps, hop) re-reads the same three
+  // half vectors: with option eo_chunk = c > 0 the sequence runs on c 64-probe chunks at a time, so
+  // that its working set (3 * V * 16 B * 64 c; 50 MB per chunk at 128^2) stays in the 256 MB
+  // Infinity Cache from the second launch on instead of streaming 201 MB per step through HBM.  The
+  // kernels index [row][probe] with the row stride nbp: a chunk range is a column offset.
+  const int nchunks = nbp / 64;
+  const int cw = (h->eo_chunk > 0 && h->eo_chunk < nchunks) ? h->eo_chunk : nchunks;
+  cplx* last_out = nullptr;
+  for (int c0 = 0; c0 < nchunks; c0 += cw) {
+    const int nc = std::min(cw, nchunks - c0);
+    const size_t off = (size_t)c0 * 64;
+    const dim3 grid(bpc * nc);
+    {
+      LaunchScope ls(h, T_SCHUR);
+      hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin + off, Bin + off,
+                         bp + off, a, 1.0, di, bpc);
+      KLAUNCH_CHECK();
+    }
+    cplx* cur = start;
+    cplx* nxt = other;
+    for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+      a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
+      LaunchScope ls(h, T_SCHUR);
+      hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream,
+                         (const cplx*)(cur + off), (const cplx*)(bp + off), nxt + off, a, bpc);
+      KLAUNCH_CHECK();
+      std::swap(cur, nxt);
+    }
+    last_out = cur;
+    {
+      LaunchScope ls(h, T_SCHUR);
+      hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin + off,
+                         (const cplx*)(cur + off), cur + off, a, di, di, bpc);
+      KLAUNCH_CHECK();
+    }
   }
-  cplx* cur = start;
-  cplx* nxt = other;
-  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
-    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur,
-                       (const cplx*)bp, nxt, a, bpc);
-    KLAUNCH_CHECK();
-    std::swap(cur, nxt);
-  }
-  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
-  {
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, (const cplx*)Xout,
-                       Xout, a, di, di, bpc);
-    KLAUNCH_CHECK();
-  }
+  if (last_out != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
   return 0;
 }
 
@@ -1564,6 +1582,12 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       cplx* zj = ws.Z + vec * j;
       cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
       cplxf* zj32 = z32 ? ws.Z32 + vec * j : nullptr;
+      // Last step of a cycle: vtilde_{j+1} is never used (the next cycle starts from the true
+      // residual), only h_{j+1,j} is.  With one Gram-Schmidt pass that is
+      // sqrt(|w|^2 - sum_k |h_{k,j}|^2): |w|^2 rides along in the same multidot pass over w and the
+      // orthogonalisation pass (j + 3 vector passes) is not run at all (k_fg_hess, pyth).
+      const bool last = h->pyth_last && !two_pass && j == jmax - 1 && m <= 8;   // (short cycles only:
+      // a single-pass basis of 30 vectors has lost too much orthogonality for the identity)
       if (k32) {
         // complex64 cycle: vtilde_j -> z_j -> w = A z_j -> orthogonalised vtilde_{j+1}, all stored
         // complex64 (the arithmetic of A z and of the inner products is fp64 on widened operands)
@@ -1572,14 +1596,16 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
         SWCHK((launch_stencil<cplxf, cplxf>(h, lv, 0, zj32, nullptr, w32, nbp, cplx{0.0, 0.0})));
         swk::PtrListT<cplxf> pv32;
         for (int k = 0; k <= j; ++k) pv32.p[k] = vt32(k);
-        SWCHK(multidot(h, pv32, j + 1, (const cplxf*)w32, n, nbp, ws.h1, ws.sc.svec, ws.c1));
-        if (two_pass) {
+        pv32.p[j + 1] = w32;
+        SWCHK(multidot(h, pv32, last ? j + 2 : j + 1, (const cplxf*)w32, n, nbp, ws.h1, ws.sc.svec, ws.c1));
+        if (last) {
+          // (nothing: h_{j+1,j} comes from the dots alone)
+        } else if (two_pass) {
           SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, nullptr));
           SWCHK(multidot(h, pv32, j + 1, (const cplxf*)w32, n, nbp, ws.h2, ws.sc.svec, ws.c1));
           SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm));
         } else {
           SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm));
-          HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
         }
       } else {
       if (z32) {
@@ -1593,23 +1619,27 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       }
       PtrList pv;
       for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
+      pv.p[j + 1] = w;
       // pass 1: raw dots d1 = Vt^H w, coefficients c = svec^2 d1 ; w -= Vt c
-      SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1));
-      if (two_pass) {
+      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1));
+      if (last) {
+        // (nothing: h_{j+1,j} comes from the dots alone)
+      } else if (two_pass) {
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, nullptr));
         // pass 2 (re-orthogonalisation): d2 = Vt^H w ; w -= Vt (svec^2 d2) ; ||w||^2
         SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2, ws.sc.svec, ws.c1));
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
       } else {
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
-        HIPCHK(hipMemsetAsync(ws.h2, 0, (size_t)(j + 1) * nbp * sizeof(cplx), h->stream));
       }
       }   // fp64 basis
       if (outer) HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
       {
         LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1, ws.h2,
-                           ws.nrm, tol, done);
+        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1,
+                           two_pass ? (const cplx*)ws.h2 : (const cplx*)nullptr,   // one pass: no second dots
+                           last ? (const cplx*)(ws.h1 + (size_t)(j + 1) * nbp) : (const cplx*)ws.nrm,
+                           tol, done, last ? 1 : 0);
         KLAUNCH_CHECK();
       }
       // read the flag back from the hinted iteration on, at the end of the budget, and in any
@@ -2682,6 +2712,15 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "inner_cgs2") == 0) {
     h->inner_cgs2 = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "eo_chunk") == 0) {
+    if (value < 0.0 || value > 1024.0) return sw_fail(h, "eo_chunk must be in [0, 1024]");
+    h->eo_chunk = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "pyth_last") == 0) {
+    h->pyth_last = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "precond_f32") == 0) {

@@ -2021,21 +2021,20 @@ __global__ void k_fg_begin(FgScalars s, const cplx* __restrict__ d, int first_cy
 // (the orthogonalisation coefficients svec_k^2 d_k come from k_reduce_partials).
 __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
                           const cplx* __restrict__ h2, const cplx* __restrict__ nrm2, double tol,
-                          int iter_base) {
+                          int iter_base, int pyth) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= s.nbp) return;
   const int m = s.m, nbp = s.nbp;
   const double sj = s.svec[(size_t)j * nbp + col].x;
-  const double wn = sqrt(fmax(nrm2[col].x, 0.0));
-  const double hn = sj * wn;
   // apply the previous rotations
   const double s0 = s.svec[col].x * sj;
-  cplx hk = cadd(h1[col], h2[col]);
+  cplx hk = h2 ? cadd(h1[col], h2[col]) : h1[col];     // h2 == NULL: one Gram-Schmidt pass
   hk = cmake(s0 * hk.x, s0 * hk.y);
   double hcol2 = hk.x * hk.x + hk.y * hk.y;      // |h_{0..j,j}|^2 before the rotations
   for (int k = 0; k < j; ++k) {
     const double sk1 = s.svec[(size_t)(k + 1) * nbp + col].x * sj;
-    cplx hk1 = cadd(h1[(size_t)(k + 1) * nbp + col], h2[(size_t)(k + 1) * nbp + col]);
+    cplx hk1 = h1[(size_t)(k + 1) * nbp + col];
+    if (h2) hk1 = cadd(hk1, h2[(size_t)(k + 1) * nbp + col]);
     hk1 = cmake(sk1 * hk1.x, sk1 * hk1.y);
     hcol2 = fma(hk1.x, hk1.x, fma(hk1.y, hk1.y, hcol2));
     const double c = s.cs[(size_t)k * nbp + col].x;
@@ -2047,6 +2046,23 @@ __global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
     cfma(u, cmake(-sn.x, sn.y), hk);
     s.H[((size_t)k * m + j) * nbp + col] = t;
     hk = u;
+  }
+  // h_{j+1,j} = hn.  pyth == 0: nrm2 = |vtilde_{j+1}|^2 of the orthogonalised vector.  pyth == 1
+  // (last step of a restart cycle, whose vtilde_{j+1} is never used and therefore never formed):
+  // nrm2 = |A ztilde_j|^2 BEFORE the orthogonalisation, and with one classical Gram-Schmidt pass
+  // |h_{j+1,j}|^2 = svec_j^2 |A ztilde_j|^2 - sum_k |h_{k,j}|^2; a remainder below 1e-12 of the
+  // total is round-off of that subtraction and counts as breakdown (the solve is then settled by
+  // the true-residual verification)
+  double wn, hn;
+  if (pyth) {
+    const double tot = sj * sj * fmax(nrm2[col].x, 0.0);
+    double h2v = tot - hcol2;
+    if (!(h2v > 1.0e-12 * tot)) h2v = 0.0;
+    hn = sqrt(h2v);
+    wn = (sj > 0.0) ? hn / sj : 0.0;
+  } else {
+    wn = sqrt(fmax(nrm2[col].x, 0.0));
+    hn = sj * wn;
   }
   // new rotation annihilating h_{j+1,j} = hn
   const double habs = sqrt(hk.x * hk.x + hk.y * hk.y);

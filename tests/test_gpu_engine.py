@@ -163,6 +163,27 @@ def test_solve_reaches_tolerance_and_matches_lu(p16, p128):
     assert true_rel.max() < 5e-12
 
 
+def test_cycle_end_step_without_orthogonalisation_pass(p16, p128):
+    """option pyth_last (default on): the last Arnoldi step of every restart cycle takes h_{j+1,j}
+    from |A z|^2 - sum |h_kj|^2 and never forms the unused next basis vector.  Same solves, same
+    iteration counts (+-1) as with the pass; every probe verified against its true residual."""
+    for p in (p16, p128):
+        n = p.A.shape[0]
+        B = _rand((70, n), 52)
+        out = {}
+        try:
+            for flag in (1, 0):
+                p.eng.set_option("pyth_last", flag)
+                X, iters, relres = p.mg.solve_batch(0, B, 1e-12)
+                true_rel = np.linalg.norm(B.T - p.A @ X.T, axis=0) / np.linalg.norm(B.T, axis=0)
+                assert true_rel.max() < 5e-12, (flag, true_rel.max())
+                out[flag] = (X, np.asarray(iters))
+        finally:
+            p.eng.set_option("pyth_last", 1)
+        assert np.abs(out[1][1] - out[0][1]).max() <= 1, (out[1][1], out[0][1])
+        assert _relerr(out[1][0], out[0][0]) < 1e-9
+
+
 def test_zero_rhs_and_single_rhs(p16):
     n = p16.A.shape[0]
     x, its, rr = p16.eng.solve(SOLVER_HID, 0, np.zeros(n, dtype=complex), 1e-12, 100)

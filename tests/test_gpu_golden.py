@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 from deflatedmlmc_schwinger_amd import gateway, matrix, utils  # noqa: E402
 from deflatedmlmc_schwinger_amd.engine import (MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP)  # noqa: E402
 from deflatedmlmc_schwinger_amd.multigrid import MG  # noqa: E402
+from oracle import ref_path as rp  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 G = json.load(open(os.path.join(HERE, "golden", "golden.json")))
@@ -134,3 +135,50 @@ def test_config2_as_written_two_level_plain_hutchinson():
     Y = mg.engine.coarsest(0, X)
     ref = (np.asarray(mg.coarsest_inv) @ X.T).T
     assert np.linalg.norm(Y - ref) / np.linalg.norm(ref) < 1e-12
+
+
+def test_benchmarked_path_full_batch_per_probe_parity():
+    """What bench.py times, checked probe by probe: the tuned solver hierarchy (32768/4096/1024, built
+    on the device, even-odd smoothing on both levels, GMRES(3)), a full batch of 256 probes GENERATED on
+    the device at a mid-stream position (the block of rank 1, stream 2, step 1 of a 2-rank run), deflated
+    Hutchinson with k = 8 -- all 256 estimates against the sparse-LU oracle at 1e-10 relative, the
+    probe codes bit for bit against np.random's legacy stream, and the same batch uploaded from the
+    host giving the same estimates."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    from deflatedmlmc_schwinger_amd.engine import ProbeStream
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    params['solver_cfg'] = dict(hierarchy.TUNED_SOLVER_CFG_128)
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "hutchinson")
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs=tp['accuracy_mg_eigvs'], sys_type='schwinger', params=tp)
+    assert mg.solver_info["levels"] == [32768, 4096, 1024]
+    Ux, tr1 = utils.deflation_pre_computations(A, tp['nr_deflat_vctrs'], tp['defl_eigvs_tol_Hutch'],
+                                               "hutchinson", mg.timer, tp, mg)
+    eng = mg.engine
+    n, nb = A.shape[0], 256
+    world, ne, rank, e, s = 2, 3, 1, 2, 1
+    first = ((s * world + rank) * ne + e) * nb          # bench.py first_probe()
+    eng.stream_set(ProbeStream(123456).window())
+    eng.probes_generate(0, 0, nb, first * n)
+    eng.probes_select(0)
+    eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
+    ests, itf, _ = eng.hutch_fetch()
+    # the same probes from NumPy's legacy global stream (utils.py:213-216 draws randint(2) per entry)
+    np.random.seed(123456)
+    for _ in range(first // nb):
+        np.random.randint(2, size=nb * n)               # the batches ahead of this block
+    probes = (2 * np.random.randint(2, size=(nb, n)) - 1).astype(np.int8)
+    assert np.array_equal(eng.probes_fetch(0), probes)
+    e_up, itf_up, _ = eng.hutch_batch(MODE_HUTCHINSON, 0, probes, 1e-12, 1000)
+    assert np.max(np.abs(e_up - ests) / np.abs(ests)) < 1e-10
+    lu = rp.LUSolver(A)
+    PT = mg.ml.levels[0].Pperm.transpose()
+    worst = 0.0
+    for k in range(nb):
+        ref = rp.hutch_probe(probes[k].astype(np.complex128), lu, Ux, PT)
+        worst = max(worst, abs(ests[k] - ref) / abs(ref))
+    assert worst < 1e-10, worst
+    assert 1 <= itf.min() and itf.max() <= 14, (itf.min(), itf.max())

@@ -141,7 +141,8 @@ def test_benchmarked_path_full_batch_per_probe_parity():
     """What bench.py times, checked probe by probe: the tuned solver hierarchy (32768/4096/1024, built
     on the device, even-odd smoothing on both levels, GMRES(3)), a full batch of 256 probes GENERATED on
     the device at a mid-stream position (the block of rank 1, stream 2, step 1 of a 2-rank run), deflated
-    Hutchinson with k = 8 -- all 256 estimates against the sparse-LU oracle at 1e-10 relative, the
+    Hutchinson with k = 8 -- all 256 estimates against the sparse-LU oracle at 1e-10 relative (see the
+    note on near-cancelling estimates below), the
     probe codes bit for bit against np.random's legacy stream, and the same batch uploaded from the
     host giving the same estimates."""
     from deflatedmlmc_schwinger_amd import hierarchy
@@ -176,9 +177,19 @@ def test_benchmarked_path_full_batch_per_probe_parity():
     assert np.max(np.abs(e_up - ests) / np.abs(ests)) < 1e-10
     lu = rp.LUSolver(A)
     PT = mg.ml.levels[0].Pperm.transpose()
-    worst = 0.0
-    for k in range(nb):
-        ref = rp.hutch_probe(probes[k].astype(np.complex128), lu, Ux, PT)
-        worst = max(worst, abs(ests[k] - ref) / abs(ref))
-    assert worst < 1e-10, worst
+    refs = np.array([rp.hutch_probe(probes[k].astype(np.complex128), lu, Ux, PT) for k in range(nb)])
+    rel = np.abs(ests - refs) / np.abs(refs)
+    order = np.argsort(rel)[::-1][:5]
+    detail = [(int(k), float(rel[k]), float(abs(refs[k])), float(abs(ests[k] - refs[k]))) for k in order]
+    print("worst five (probe, rel, |ref|, |diff|):", detail, "median |ref| %.1f" % np.median(np.abs(refs)))
+    # e = x^H z is a sum of 32768 terms that cancels to anything between 0 and a few hundred (median
+    # |e| ~ 140 here, probe 63 of this block: 2.9); a solve to a 1e-12 residual fixes e to an ABSOLUTE
+    # 2-6e-10 for every probe (measured), whatever it cancels to.  So: 1e-10 relative to |e| for every
+    # probe whose estimate is not more than ten times below the batch's typical magnitude, and 1e-10
+    # relative to that floor for the (rare) ones that are.
+    floor = 0.1 * np.median(np.abs(refs))
+    scaled = np.abs(ests - refs) / np.maximum(np.abs(refs), floor)
+    assert scaled.max() < 1e-10, detail
+    assert np.all(rel[np.abs(refs) >= floor] < 1e-10), detail
+    assert np.mean(rel < 1e-10) >= 0.99, detail
     assert 1 <= itf.min() and itf.max() <= 14, (itf.min(), itf.max())

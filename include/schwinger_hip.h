@@ -152,8 +152,24 @@ int sw_set_rhsmap(sw_engine* h, int level, int n, const int64_t* indptr, const i
  * precondition level-0 solves (0 or 1). */
 int sw_set_solver(sw_engine* h, int restart, int solver_hid);
 
-/* Engine switches for A/B measurements: "use_mfma" (1/0): fp64-MFMA block-row kernels for the
- * dense coarsest inverse and block-structured coarse operators vs the grouped-ELL kernels. */
+/* Engine switches (defaults are the measured-best settings; everything else exists for A/B runs,
+ * profiles/ holds the measurements).  Unknown names and out-of-range values fail with a message.
+ *   solver:        "precond_f32" (0) multigrid cycle in complex64 inside the fp64 FGMRES; "f32_krylov" (1)
+ *                  with it, complex64 Krylov basis per restart cycle; "cgs2" (0) / "inner_cgs2" (0) second
+ *                  Gram-Schmidt pass; "pyth_last" (1) last Arnoldi step of a restart cycle without its
+ *                  orthogonalisation pass; "verify" (1) true-residual check of every outer solve;
+ *                  "lazy_sync" (1) convergence read-back only near the expected iteration count;
+ *                  "dot_blocks" row blocks of the reducing BLAS-1 launches
+ *   stencil level: "stencil_spw", "stencil_tile", "stencil_nt" (sites per wave, lattice tile width,
+ *                  non-temporal stores); "fuse_smoother" / "fuse_lds" (0) two polynomial steps per launch;
+ *                  "eo_chunk" (0) even-odd smoothing on this many 64-probe chunks at a time; "p_even" (1)
+ *                  prolongation onto the even sites only ahead of an even-odd smoother
+ *   block levels:  "use_mfma" (1) fp64-MFMA block-row kernels vs grouped ELL; "mfma_ops", "mfma_tiles",
+ *                  "mfma_small_tiles", "bsr_stages" / "dense_stages" (register pipeline depth), "bsr_nt",
+ *                  "bsr_xreg", "bsr_sub", "dense_map", "bsr_splitk", "ell_order"; complex64 twins "f32_tiles",
+ *                  "f32_stages", "f32_dense_stages", "f32_splitk", "f32_pairs"
+ *   sw_bench_dirac: "bench_mode" (0 Y=AX, 1 residual, 2 smoother step), "bench_what" (operator / R / P /
+ *                  coarsest) */
 int sw_set_option(sw_engine* h, const char* name, double value);
 
 /* ---- building blocks (host buffers, reference ordering) -------------------------------- */

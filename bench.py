@@ -337,7 +337,8 @@ def run(args):
     kstats = {name: eng.kernel_stats(cls) for name, cls in
               (("k_stencil<0>", 8), ("k_stencil<1>", 9), ("k_stencil<2>", 10),
                ("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
-               ("k_bsr_mfma(level-2 operator)", 14), ("k_schur_step", 15))}
+               ("k_bsr_mfma(level-2 operator)", 14), ("k_schur_step", 15),
+               ("k_schur_step<0/1> (S x, b' - S x)", 16))}
     kwork = {name: eng.kernel_work(cls) for name, cls in
              (("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
               ("k_bsr_mfma(level-2 operator)", 14))}
@@ -361,6 +362,9 @@ def run(args):
             "k_stencil<2>": ("hbm", V * (96.0 * nbp + 32.0)),              # fused smoother step
             # even-odd smoother step / hop: three HALF-vector passes (x_e, b'_e in, x_e out) + links
             "k_schur_step": ("hbm", 0.5 * V * (96.0 * nbp + 64.0)),
+            # operator of the even-odd reduced system (outer Krylov solver on half vectors): two
+            # half-vector passes (the few residual launches, three, are counted at the same figure)
+            "k_schur_step<0/1> (S x, b' - S x)": ("hbm", 0.5 * V * (64.0 * nbp + 64.0)),
             "k_bsr_mfma(dense coarsest)": ("mfma", 8.0 * nc * nc * nbp),
             "k_bsr_mfma(level-1 operator)": ("mfma", 8.0 * levels[1] * 80.0 * nbp
                                              if len(levels) > 2 else 0.0),

@@ -53,6 +53,7 @@ enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER
                 T_STENCIL_SM2,  // k_stencil_2step: two fused smoother steps
                 T_MFMA_OP2,     // k_bsr_mfma on level operators below level 1 of the solver hierarchy
                 T_SCHUR,        // k_schur_step / k_eo_hop: even-odd smoother of the stencil level
+                T_SCHUR_OP,     // k_schur_step<0/1>: operator / residual of the even-odd reduced system
                 T_NCAT };
 // classes >= T_STENCIL are folded into the mvm / coarsest buckets by sw_timers and reported
 // separately by sw_kernel_stats
@@ -110,6 +111,7 @@ struct Level {
   cplx* U1 = nullptr;
   cplx* U2 = nullptr;
   EllOp A, P, R;
+  EllOp Re;   // stencil level, even-odd reduced outer solve: R restricted to the even-site columns
   int nu_pre = 0, nu_post = 3, kcycle = 0;
   // fixed-polynomial (Richardson) smoother: weights 1/theta_k; empty -> adaptive MR steps
   std::vector<std::complex<double>> w_pre, w_post;
@@ -204,6 +206,9 @@ struct sw_engine {
   bool pyth_last = true;
   // even-odd smoothing of the stencil level on this many 64-probe chunks at a time (0: all at once)
   int eo_chunk = 0;
+  // outer solves of an even-odd smoothed stencil level on the even-odd reduced (Schur complement)
+  // system: half-length Krylov vectors, see fgmres_eo
+  bool eo_solve = true;
   // single-precision preconditioner: every application of a multigrid cycle as the preconditioner of
   // an fp64 flexible GMRES (and sw_vcycle) runs in complex64 on the f32 matrix cores -- operands cast
   // at the boundary, residuals / orthogonalisation / verification stay fp64
@@ -1027,6 +1032,45 @@ static int ensure_even_orders(sw_engine* h, Hier& H) {
     SWCHK(dev_free(h, P.order_even));
     P.order_even = nullptr;
     P.ngroups_even = 0;
+    SWCHK(free_op(h, lv.Re));
+    if (lv.stencil && !lv.w_eo.empty() && lv.R.set && lv.R.cols && lv.R.vals) {
+      // R restricted to the columns of the even sites (the first n / 2 rows of the level), compacted:
+      // the restriction of a vector whose odd half is zero, read from a half-length array
+      const EllOp& R = lv.R;
+      const size_t ng = (size_t)R.ngroups, K = (size_t)R.K, G = (size_t)R.G;
+      std::vector<int> rc(ng * K);
+      std::vector<std::complex<double>> rv(ng * K * G);
+      HIPCHK(hipMemcpy(rc.data(), R.cols, rc.size() * sizeof(int), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(rv.data(), R.vals, rv.size() * sizeof(cplx), hipMemcpyDeviceToHost));
+      std::vector<std::vector<size_t>> keep(ng);
+      size_t Ke = 1;
+      for (size_t g = 0; g < ng; ++g) {
+        for (size_t k = 0; k < K; ++k) {
+          if (rc[g * K + k] >= lv.n / 2) continue;
+          bool nz = false;
+          for (size_t q = 0; q < G; ++q) nz = nz || rv[(g * K + k) * G + q] != std::complex<double>(0.0, 0.0);
+          if (nz) keep[g].push_back(k);
+        }
+        Ke = std::max(Ke, keep[g].size());
+      }
+      std::vector<int> ec(ng * Ke, 0);
+      std::vector<std::complex<double>> evv(ng * Ke * G, std::complex<double>(0.0, 0.0));
+      for (size_t g = 0; g < ng; ++g)
+        for (size_t i = 0; i < keep[g].size(); ++i) {
+          const size_t k = keep[g][i];
+          ec[g * Ke + i] = rc[g * K + k];
+          for (size_t q = 0; q < G; ++q) evv[(g * Ke + i) * G + q] = rv[(g * K + k) * G + q];
+        }
+      EllOp& E = lv.Re;
+      E.nrows = R.nrows;
+      E.ncols = lv.n / 2;
+      E.K = (int)Ke;
+      E.G = R.G;
+      E.ngroups = R.ngroups;
+      SWCHK(upload(h, &E.cols, ec.data(), ec.size()));
+      SWCHK(upload(h, &E.vals, (const cplx*)evv.data(), evv.size()));
+      E.set = true;
+    }
     if (!P.set || !P.cols || lv.w_eo.empty() || P.G < 1) continue;
     std::vector<char> even_row_tile;     // per 16-row tile (block levels)
     if (!lv.stencil) {
@@ -1128,6 +1172,224 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
     }
   }
   if (last_out != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Outer solve of an even-odd smoothed stencil level on the EVEN-ODD REDUCED system.
+//   A x = b  <=>  S x_e = b'_e,  b'_e = b_e - A_eo A_oo^-1 b_o,  x_o = A_oo^-1 (b_o - A_oe x_e),
+//   S = A_ee - A_eo A_oo^-1 A_oe  (here A_oo = D, the Schur complement k_schur_step applies).
+// The cycle's even-odd smoother leaves the odd residual exactly zero, so in the full-system FGMRES the
+// odd halves of all Krylov vectors carry no information; here they do not exist: every vector of the
+// Krylov solver (basis, directions, iterate, residual) is a HALF vector -- the first n / 2 rows of
+// the parity-sorted level --, the operator is one k_schur_step<0> (two half passes instead of the
+// stencil's four), and the preconditioner is the even block of the same multigrid cycle,
+// M_S r_e = [M (r_e; 0)]_e ~ (A^-1)_ee = S^-1: restriction from the even columns only (Level::Re), no
+// hop before the Schur steps (b_o = 0 makes b' = r_e) and none after them (the odd half is not
+// needed).  The residual of the reduced system IS the residual of the full one (its odd half vanishes
+// identically once x_o is set from x_e), and it is measured against ||b|| of the full system, so the
+// stopping criterion is the reference's (multigrid.py:347-366).  Per iteration on the lattice level:
+// about 47 half-vector passes instead of 64.
+// ---------------------------------------------------------------------------------------------
+static swk::StencilArgs eo_stencil_args(sw_engine* h, Level& lv, int nbp) {
+  swk::StencilArgs a;
+  a.L = lv.L;
+  a.Vh = lv.L * lv.L / 2;
+  a.diag = 4.0 + lv.mass;
+  a.U1 = lv.U1;
+  a.U2 = lv.U2;
+  a.nbp = nbp;
+  a.nt_store = 0;
+  a.tile_w = lv.L;
+  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
+  a.w = cplx{0.0, 0.0};
+  return a;
+}
+
+// Y_e = S X_e (mode 0) or Bp_e - S X_e (mode 1); all three are half vectors
+static int schur_apply(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* Bp, cplx* Y, int nbp) {
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  LaunchScope ls(h, T_SCHUR_OP);
+  if (mode == 0)
+    hipLaunchKernelGGL((swk::k_schur_step<cplx, 0>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
+  else
+    hipLaunchKernelGGL((swk::k_schur_step<cplx, 1>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+static int ensure_even_orders(sw_engine* h, Hier& H);
+static bool eo_solve_eligible(sw_engine* h, Hier& H, int level) {
+  if (!h->eo_solve || level != 0 || H.nlevels < 2) return false;
+  Level& lv = H.lv[0];
+  if (!(lv.stencil && lv.rich && lv.gm_m == 0 && !lv.w_eo.empty() && lv.w_pre.empty() && lv.P.set &&
+        lv.R.set && !h->precond_f32 && !h->cgs2 && h->p_even && (lv.n % 2 == 0)))
+    return false;
+  if (ensure_even_orders(h, H) != 0) return false;
+  return lv.Re.set && lv.P.order_even != nullptr;
+}
+
+// Xout_e = [M (Bin_e; 0)]_e : the even block of the level-0 cycle (see above); half vectors in and out
+static int vcycle_even(sw_engine* h, Hier& H, const cplx* Bin, cplx* Xout, int nbp) {
+  Level& lv = H.lv[0];
+  Level& lc = H.lv[1];
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  SWCHK(ensure_level_ws(h, lc, nbp));
+  SWCHK(ensure_even_orders(h, H));
+  if (!lv.Re.set) return sw_fail(h, "internal: even-column restrictor missing");
+  SWCHK(launch_ell(h, lv.Re, 0, Bin, nullptr, lc.b, nbp, T_R));
+  SWCHK(coarse_correction(h, H, 0, nbp));
+  // ping-pong between lv.t and Xout (only their even halves are touched) so that the last step lands in Xout
+  const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+  cplx* cur = odd_steps ? lv.t : Xout;
+  cplx* nxt = odd_steps ? Xout : lv.t;
+  // (Xout is a HALF-length array: the prolongation must write the even sites only)
+  if (!(lv.P.order_even && h->p_even))
+    return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
+  SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, cur, nbp, T_P, cplx{0.0, 0.0}, true));
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur, Bin, nxt,
+                       a, bpc);
+    KLAUNCH_CHECK();
+    std::swap(cur, nxt);
+  }
+  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
+  return 0;
+}
+
+// batched flexible GMRES(m) on the even-odd reduced system of the stencil level (fp64, one Gram-Schmidt
+// pass, same scalar kernels, freezing, lazy read-back and true-residual verification as fgmres)
+static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, int maxiter, int m,
+                     KrylovWS& ws, int nbp, int* iters_total) {
+  Level& lv = H.lv[0];
+  const int hid_idx = (int)(&H - &h->hier[0]);
+  const int check_from = h->lazy_sync ? std::max(0, h->sync_hint[hid_idx][0] - 2) : 0;
+  const int n2 = lv.n / 2;
+  const size_t vec = (size_t)n2 * nbp;
+  const int tb = 256, tg = (nbp + tb - 1) / tb;
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  const double di = 1.0 / a.diag;
+  cplx* bp = ws.xacc;               // b'_e
+  {
+    // ||b|| of the FULL system fixes normb (the reference's stopping criterion); b'_e = b_e + H_eo b_o / D
+    PtrList pl;
+    pl.p[0] = B;
+    SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm));
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 1, tol);
+      KLAUNCH_CHECK();
+    }
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, B, B, bp, a, 1.0, di, bpc);
+    KLAUNCH_CHECK();
+  }
+  // the iterate lives in the even half of X; its odd half is set once at the end
+  {
+    LaunchScope ls(h, T_AXPY);
+    HIPCHK(hipMemsetAsync(X, 0, vec * sizeof(cplx), h->stream));
+  }
+  int done = 0;
+  bool converged = false;
+  const cplx* Rcur = bp;
+  while (done < maxiter && !converged) {
+    {
+      PtrList pl;
+      pl.p[0] = Rcur;
+      SWCHK(multidot(h, pl, 1, Rcur, n2, nbp, ws.nrm));
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 0, tol);
+      KLAUNCH_CHECK();
+    }
+    auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
+    int j = 0;
+    const int jmax = std::min(m, maxiter - done);
+    for (; j < jmax; ++j) {
+      cplx* zj = ws.Z + vec * j;
+      cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
+      const bool last = h->pyth_last && j == jmax - 1 && m <= 8;
+      SWCHK(vcycle_even(h, H, vt(j), zj, nbp));
+      SWCHK(schur_apply(h, lv, 0, zj, nullptr, w, nbp));
+      PtrList pv;
+      for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
+      pv.p[j + 1] = w;
+      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n2, nbp, ws.h1, ws.sc.svec, ws.c1));
+      if (!last) SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n2, nbp, ws.nrm));
+      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
+      {
+        LaunchScope ls(h, T_OTHER);
+        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1,
+                           (const cplx*)nullptr,
+                           last ? (const cplx*)(ws.h1 + (size_t)(j + 1) * nbp) : (const cplx*)ws.nrm,
+                           tol, done, last ? 1 : 0);
+        KLAUNCH_CHECK();
+      }
+      if (done + j + 1 >= check_from || done + j + 1 >= maxiter || ((done + j + 1) & 7) == 0) {
+        HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        SWCHK(stream_sync(h));
+        if (*h->h_notconv == 0) {
+          converged = true;
+          ++j;
+          break;
+        }
+      }
+    }
+    const int k = j;
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fg_solve, dim3(tg), dim3(tb), 0, h->stream, ws.sc, k);
+      KLAUNCH_CHECK();
+    }
+    {
+      PtrList pz;
+      for (int q = 0; q < k; ++q) pz.p[q] = ws.Z + vec * q;
+      SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n2, nbp, nullptr));
+    }
+    done += k;
+    if (converged && h->verify) {
+      // true residual of the reduced system = true residual of the full one
+      SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
+      PtrList pr;
+      pr.p[0] = ws.rres;
+      SWCHK(multidot(h, pr, 1, ws.rres, n2, nbp, ws.nrm));
+      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
+      {
+        LaunchScope ls(h, T_OTHER);
+        hipLaunchKernelGGL(swk::k_fg_verify, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, tol);
+        KLAUNCH_CHECK();
+      }
+      HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      SWCHK(stream_sync(h));
+      if (*h->h_notconv != 0) {
+        converged = false;
+        Rcur = ws.rres;
+        continue;
+      }
+    } else if (!converged && done < maxiter) {
+      SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
+      Rcur = ws.rres;
+    }
+  }
+  {
+    // x_o = (b_o + H_oe x_e) / D
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, B, (const cplx*)X, X, a, di, di,
+                       bpc);
+    KLAUNCH_CHECK();
+  }
+  if (iters_total) *iters_total = done;
+  h->sync_hint[hid_idx][0] = converged ? done : 0;
   return 0;
 }
 
@@ -1830,6 +2092,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(free_op(h, lv.A));
     SWCHK(free_op(h, lv.P));
     SWCHK(free_op(h, lv.R));
+    SWCHK(free_op(h, lv.Re));
     for (int q = 0; q < 4; ++q) SWCHK(free_op(h, lv.eo_op[q]));
     SWCHK(dev_free(h, lv.rowmap));
     SWCHK(dev_free(h, lv.b)); SWCHK(dev_free(h, lv.x)); SWCHK(dev_free(h, lv.r));
@@ -2714,6 +2977,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->inner_cgs2 = value != 0.0;
     return 0;
   }
+  if (std::strcmp(name, "eo_solve") == 0) {
+    h->eo_solve = value != 0.0;
+    return 0;
+  }
   if (std::strcmp(name, "eo_chunk") == 0) {
     if (value < 0.0 || value > 1024.0) return sw_fail(h, "eo_chunk must be in [0, 1024]");
     h->eo_chunk = (int)value;
@@ -2951,6 +3218,7 @@ static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, 
   }
   const int m = std::min(h->restart, std::max(1, maxiter));
   SWCHK(ensure_krylov(h, lv.sws, m, lv.n, nbp, true));
+  if (eo_solve_eligible(h, H, level0)) return fgmres_eo(h, H, B, X, tol, maxiter, m, lv.sws, nbp, total);
   return fgmres(h, H, level0, B, X, tol, maxiter, m, true, lv.sws, nbp, total);
 }
 
@@ -3513,7 +3781,7 @@ int sw_timers(sw_engine* h, double t[8]) {
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
   t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP] +
-              h->tacc[T_STENCIL_SM2] + h->tacc[T_MFMA_OP2] + h->tacc[T_SCHUR];
+              h->tacc[T_STENCIL_SM2] + h->tacc[T_MFMA_OP2] + h->tacc[T_SCHUR] + h->tacc[T_SCHUR_OP];
   t[T_COARSEST] += h->tacc[T_MFMA_DENSE];
   return 0;
 }

@@ -535,7 +535,9 @@ __global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const C* __restrict__ Uv,
 }
 
 // Y_e = X_e + w (Bp_e - S X_e),  S = D - H_eo H_oe / D : both hops in one kernel (even sites only)
-template <class C>
+// MODE 2: that smoother step;  MODE 0: Y_e = S X_e;  MODE 1: Y_e = Bp_e - S X_e  (operator and residual
+// of the even-odd reduced system the outer Krylov solver works on, fgmres_eo)
+template <class C, int MODE = 2>
 __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X,
                                                          const C* __restrict__ Bp,
                                                          C* __restrict__ Y, StencilArgsT<C> a,
@@ -594,13 +596,27 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
   const size_t r = eo_row(x, y, L, Vh);
   const real d = a.diag, di = (real)1 / a.diag;
   const C c0 = Xc[r * nbp], c1 = Xc[(r + 1) * nbp];
-  const C q0 = Bp[r * nbp + col], q1 = Bp[(r + 1) * nbp + col];
+  C q0 = czero<C>(), q1 = q0;
+  if (MODE != 0) {
+    q0 = Bp[r * nbp + col];
+    q1 = Bp[(r + 1) * nbp + col];
+  }
   // residual of S: b' - (D x - acc / D)
   const C r0 = cschur(q0, d, c0, di, acc.s0);
   const C r1 = cschur(q1, d, c1, di, acc.s1);
-  C o0 = c0, o1 = c1;
-  cfma(o0, a.w, r0);
-  cfma(o1, a.w, r1);
+  C o0, o1;
+  if (MODE == 0) {          // S x = -(0 - S x)
+    o0 = csub(czero<C>(), r0);
+    o1 = csub(czero<C>(), r1);
+  } else if (MODE == 1) {
+    o0 = r0;
+    o1 = r1;
+  } else {
+    o0 = c0;
+    o1 = c1;
+    cfma(o0, a.w, r0);
+    cfma(o1, a.w, r1);
+  }
   Y[r * nbp + col] = o0;
   Y[(r + 1) * nbp + col] = o1;
 }

@@ -1175,224 +1175,6 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Outer solve of an even-odd smoothed stencil level on the EVEN-ODD REDUCED system.
-//   A x = b  <=>  S x_e = b'_e,  b'_e = b_e - A_eo A_oo^-1 b_o,  x_o = A_oo^-1 (b_o - A_oe x_e),
-//   S = A_ee - A_eo A_oo^-1 A_oe  (here A_oo = D, the Schur complement k_schur_step applies).
-// The cycle's even-odd smoother leaves the odd residual exactly zero, so in the full-system FGMRES the
-// odd halves of all Krylov vectors carry no information; here they do not exist: every vector of the
-// Krylov solver (basis, directions, iterate, residual) is a HALF vector -- the first n / 2 rows of
-// the parity-sorted level --, the operator is one k_schur_step<0> (two half passes instead of the
-// stencil's four), and the preconditioner is the even block of the same multigrid cycle,
-// M_S r_e = [M (r_e; 0)]_e ~ (A^-1)_ee = S^-1: restriction from the even columns only (Level::Re), no
-// hop before the Schur steps (b_o = 0 makes b' = r_e) and none after them (the odd half is not
-// needed).  The residual of the reduced system IS the residual of the full one (its odd half vanishes
-// identically once x_o is set from x_e), and it is measured against ||b|| of the full system, so the
-// stopping criterion is the reference's (multigrid.py:347-366).  Per iteration on the lattice level:
-// about 47 half-vector passes instead of 64.
-// ---------------------------------------------------------------------------------------------
-static swk::StencilArgs eo_stencil_args(sw_engine* h, Level& lv, int nbp) {
-  swk::StencilArgs a;
-  a.L = lv.L;
-  a.Vh = lv.L * lv.L / 2;
-  a.diag = 4.0 + lv.mass;
-  a.U1 = lv.U1;
-  a.U2 = lv.U2;
-  a.nbp = nbp;
-  a.nt_store = 0;
-  a.tile_w = lv.L;
-  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
-  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
-  a.w = cplx{0.0, 0.0};
-  return a;
-}
-
-// Y_e = S X_e (mode 0) or Bp_e - S X_e (mode 1); all three are half vectors
-static int schur_apply(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* Bp, cplx* Y, int nbp) {
-  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
-  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
-  LaunchScope ls(h, T_SCHUR_OP);
-  if (mode == 0)
-    hipLaunchKernelGGL((swk::k_schur_step<cplx, 0>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
-  else
-    hipLaunchKernelGGL((swk::k_schur_step<cplx, 1>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
-  KLAUNCH_CHECK();
-  return 0;
-}
-
-static int ensure_even_orders(sw_engine* h, Hier& H);
-static bool eo_solve_eligible(sw_engine* h, Hier& H, int level) {
-  if (!h->eo_solve || level != 0 || H.nlevels < 2) return false;
-  Level& lv = H.lv[0];
-  if (!(lv.stencil && lv.rich && lv.gm_m == 0 && !lv.w_eo.empty() && lv.w_pre.empty() && lv.P.set &&
-        lv.R.set && !h->precond_f32 && !h->cgs2 && h->p_even && (lv.n % 2 == 0)))
-    return false;
-  if (ensure_even_orders(h, H) != 0) return false;
-  return lv.Re.set && lv.P.order_even != nullptr;
-}
-
-// Xout_e = [M (Bin_e; 0)]_e : the even block of the level-0 cycle (see above); half vectors in and out
-static int vcycle_even(sw_engine* h, Hier& H, const cplx* Bin, cplx* Xout, int nbp) {
-  Level& lv = H.lv[0];
-  Level& lc = H.lv[1];
-  SWCHK(ensure_level_ws(h, lv, nbp));
-  SWCHK(ensure_level_ws(h, lc, nbp));
-  SWCHK(ensure_even_orders(h, H));
-  if (!lv.Re.set) return sw_fail(h, "internal: even-column restrictor missing");
-  SWCHK(launch_ell(h, lv.Re, 0, Bin, nullptr, lc.b, nbp, T_R));
-  SWCHK(coarse_correction(h, H, 0, nbp));
-  // ping-pong between lv.t and Xout (only their even halves are touched) so that the last step lands in Xout
-  const bool odd_steps = (lv.w_eo.size() & 1) != 0;
-  cplx* cur = odd_steps ? lv.t : Xout;
-  cplx* nxt = odd_steps ? Xout : lv.t;
-  // (Xout is a HALF-length array: the prolongation must write the even sites only)
-  if (!(lv.P.order_even && h->p_even))
-    return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
-  SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, cur, nbp, T_P, cplx{0.0, 0.0}, true));
-  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
-  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
-  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
-    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur, Bin, nxt,
-                       a, bpc);
-    KLAUNCH_CHECK();
-    std::swap(cur, nxt);
-  }
-  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
-  return 0;
-}
-
-// batched flexible GMRES(m) on the even-odd reduced system of the stencil level (fp64, one Gram-Schmidt
-// pass, same scalar kernels, freezing, lazy read-back and true-residual verification as fgmres)
-static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, int maxiter, int m,
-                     KrylovWS& ws, int nbp, int* iters_total) {
-  Level& lv = H.lv[0];
-  const int hid_idx = (int)(&H - &h->hier[0]);
-  const int check_from = h->lazy_sync ? std::max(0, h->sync_hint[hid_idx][0] - 2) : 0;
-  const int n2 = lv.n / 2;
-  const size_t vec = (size_t)n2 * nbp;
-  const int tb = 256, tg = (nbp + tb - 1) / tb;
-  SWCHK(ensure_level_ws(h, lv, nbp));
-  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
-  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
-  const double di = 1.0 / a.diag;
-  cplx* bp = ws.xacc;               // b'_e
-  {
-    // ||b|| of the FULL system fixes normb (the reference's stopping criterion); b'_e = b_e + H_eo b_o / D
-    PtrList pl;
-    pl.p[0] = B;
-    SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm));
-    {
-      LaunchScope ls(h, T_OTHER);
-      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 1, tol);
-      KLAUNCH_CHECK();
-    }
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, B, B, bp, a, 1.0, di, bpc);
-    KLAUNCH_CHECK();
-  }
-  // the iterate lives in the even half of X; its odd half is set once at the end
-  {
-    LaunchScope ls(h, T_AXPY);
-    HIPCHK(hipMemsetAsync(X, 0, vec * sizeof(cplx), h->stream));
-  }
-  int done = 0;
-  bool converged = false;
-  const cplx* Rcur = bp;
-  while (done < maxiter && !converged) {
-    {
-      PtrList pl;
-      pl.p[0] = Rcur;
-      SWCHK(multidot(h, pl, 1, Rcur, n2, nbp, ws.nrm));
-      LaunchScope ls(h, T_OTHER);
-      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 0, tol);
-      KLAUNCH_CHECK();
-    }
-    auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
-    int j = 0;
-    const int jmax = std::min(m, maxiter - done);
-    for (; j < jmax; ++j) {
-      cplx* zj = ws.Z + vec * j;
-      cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
-      const bool last = h->pyth_last && j == jmax - 1 && m <= 8;
-      SWCHK(vcycle_even(h, H, vt(j), zj, nbp));
-      SWCHK(schur_apply(h, lv, 0, zj, nullptr, w, nbp));
-      PtrList pv;
-      for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
-      pv.p[j + 1] = w;
-      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n2, nbp, ws.h1, ws.sc.svec, ws.c1));
-      if (!last) SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n2, nbp, ws.nrm));
-      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
-      {
-        LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1,
-                           (const cplx*)nullptr,
-                           last ? (const cplx*)(ws.h1 + (size_t)(j + 1) * nbp) : (const cplx*)ws.nrm,
-                           tol, done, last ? 1 : 0);
-        KLAUNCH_CHECK();
-      }
-      if (done + j + 1 >= check_from || done + j + 1 >= maxiter || ((done + j + 1) & 7) == 0) {
-        HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        SWCHK(stream_sync(h));
-        if (*h->h_notconv == 0) {
-          converged = true;
-          ++j;
-          break;
-        }
-      }
-    }
-    const int k = j;
-    {
-      LaunchScope ls(h, T_OTHER);
-      hipLaunchKernelGGL(swk::k_fg_solve, dim3(tg), dim3(tb), 0, h->stream, ws.sc, k);
-      KLAUNCH_CHECK();
-    }
-    {
-      PtrList pz;
-      for (int q = 0; q < k; ++q) pz.p[q] = ws.Z + vec * q;
-      SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n2, nbp, nullptr));
-    }
-    done += k;
-    if (converged && h->verify) {
-      // true residual of the reduced system = true residual of the full one
-      SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
-      PtrList pr;
-      pr.p[0] = ws.rres;
-      SWCHK(multidot(h, pr, 1, ws.rres, n2, nbp, ws.nrm));
-      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
-      {
-        LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_verify, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, tol);
-        KLAUNCH_CHECK();
-      }
-      HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      SWCHK(stream_sync(h));
-      if (*h->h_notconv != 0) {
-        converged = false;
-        Rcur = ws.rres;
-        continue;
-      }
-    } else if (!converged && done < maxiter) {
-      SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
-      Rcur = ws.rres;
-    }
-  }
-  {
-    // x_o = (b_o + H_oe x_e) / D
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, B, (const cplx*)X, X, a, di, di,
-                       bpc);
-    KLAUNCH_CHECK();
-  }
-  if (iters_total) *iters_total = done;
-  h->sync_hint[hid_idx][0] = converged ? done : 0;
-  return 0;
-}
-
 // cycle with the fixed-polynomial smoother (weights set by sw_set_smoother)
 static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout, int nbp) {
   Level& lv = H.lv[l];
@@ -1638,8 +1420,10 @@ static int launch_ell32(sw_engine* h, const EllOp& op, int mode, const cplxf* X,
 // even-odd post-smoothing of the stencil level in complex64 (eo_smooth's twin).  C = cplxf2: two probes
 // per lane (16-B accesses, rows of nbp / 2 elements), used whenever nbp is a multiple of 128
 template <class C>
+// reduced: smoothing of the even-odd reduced system itself (vcycle32_even): Bin IS b'_e (no hop before the
+// steps) and only the even half of the iterate is wanted (no hop after them); all arrays half-length
 static int eo_smooth32_t(sw_engine* h, Level& lv, const cplxf* Bin_, cplxf* start_, cplxf* other_,
-                         cplxf* Xout_, int nbp) {
+                         cplxf* Xout_, int nbp, bool reduced) {
   const int per = (int)(sizeof(C) / sizeof(cplxf));   // probes per lane
   const C* Bin = (const C*)Bin_;
   C* start = (C*)start_;
@@ -1661,11 +1445,11 @@ static int eo_smooth32_t(sw_engine* h, Level& lv, const cplxf* Bin_, cplxf* star
   const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
   const dim3 grid(bpc * (a.nbp / 64));
   const float di = (float)(1.0 / (4.0 + lv.mass));
-  C* bp = (C*)lv.r32;
-  {
+  const C* bp = reduced ? Bin : (const C*)lv.r32;
+  if (!reduced) {
     LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL((swk::k_eo_hop<0, C>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0f,
-                       di, bpc);
+    hipLaunchKernelGGL((swk::k_eo_hop<0, C>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, (C*)lv.r32, a,
+                       1.0f, di, bpc);
     KLAUNCH_CHECK();
   }
   C* cur = start;
@@ -1679,7 +1463,7 @@ static int eo_smooth32_t(sw_engine* h, Level& lv, const cplxf* Bin_, cplxf* star
     std::swap(cur, nxt);
   }
   if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
-  {
+  if (!reduced) {
     LaunchScope ls(h, T_SCHUR);
     hipLaunchKernelGGL((swk::k_eo_hop<1, C>), grid, dim3(SW_BLOCK), 0, h->stream, Bin,
                        (const C*)Xout, Xout, a, di, di, bpc);
@@ -1689,10 +1473,39 @@ static int eo_smooth32_t(sw_engine* h, Level& lv, const cplxf* Bin_, cplxf* star
 }
 
 static int eo_smooth32(sw_engine* h, Level& lv, const cplxf* Bin, cplxf* start, cplxf* other, cplxf* Xout,
-                       int nbp) {
+                       int nbp, bool reduced = false) {
   if (nbp % 128 == 0 && h->f32_pairs)
-    return eo_smooth32_t<swk::cplxf2>(h, lv, Bin, start, other, Xout, nbp);
-  return eo_smooth32_t<cplxf>(h, lv, Bin, start, other, Xout, nbp);
+    return eo_smooth32_t<swk::cplxf2>(h, lv, Bin, start, other, Xout, nbp, reduced);
+  return eo_smooth32_t<cplxf>(h, lv, Bin, start, other, Xout, nbp, reduced);
+}
+
+// Y_e = S X_e on complex64 half vectors (operator of the even-odd reduced system, complex64 Krylov basis)
+template <class C>
+static int schur_apply32_t(sw_engine* h, Level& lv, const cplxf* X_, cplxf* Y_, int nbp) {
+  const int per = (int)(sizeof(C) / sizeof(cplxf));
+  swk::StencilArgsT<C> a;
+  a.L = lv.L;
+  a.Vh = lv.L * lv.L / 2;
+  a.diag = (float)(4.0 + lv.mass);
+  a.U1 = lv.U1f;
+  a.U2 = lv.U2f;
+  a.nbp = nbp / per;
+  a.nt_store = 0;
+  a.tile_w = lv.L;
+  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
+  a.w = cplxf{0.f, 0.f};
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (a.nbp / 64));
+  LaunchScope ls(h, T_SCHUR_OP);
+  hipLaunchKernelGGL((swk::k_schur_step<C, 0>), grid, dim3(SW_BLOCK), 0, h->stream, (const C*)X_,
+                     (const C*)nullptr, (C*)Y_, a, bpc);
+  KLAUNCH_CHECK();
+  return 0;
+}
+static int schur_apply32(sw_engine* h, Level& lv, const cplxf* X, cplxf* Y, int nbp) {
+  if (nbp % 128 == 0 && h->f32_pairs) return schur_apply32_t<swk::cplxf2>(h, lv, X, Y, nbp);
+  return schur_apply32_t<cplxf>(h, lv, X, Y, nbp);
 }
 
 static int vcycle32(sw_engine* h, Hier& H, int l, const cplxf* Bin, cplxf* Xout, int nbp) {
@@ -3203,6 +3016,288 @@ int sw_vcycle(sw_engine* h, int hid, int level0, int nb, const double* B, double
   if (h->precond_f32 && f32_capable(H, level0)) SWCHK(vcycle_f32_boundary(h, H, level0, a, b, nbp));
   else SWCHK(vcycle(h, H, level0, a, b, nbp));
   return unpack_host(h, lv, nb, b, X, nbp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Outer solve of an even-odd smoothed stencil level on the EVEN-ODD REDUCED system.
+//   A x = b  <=>  S x_e = b'_e,  b'_e = b_e - A_eo A_oo^-1 b_o,  x_o = A_oo^-1 (b_o - A_oe x_e),
+//   S = A_ee - A_eo A_oo^-1 A_oe  (here A_oo = D, the Schur complement k_schur_step applies).
+// The cycle's even-odd smoother leaves the odd residual exactly zero, so in the full-system FGMRES the
+// odd halves of all Krylov vectors carry no information; here they do not exist: every vector of the
+// Krylov solver (basis, directions, iterate, residual) is a HALF vector -- the first n / 2 rows of
+// the parity-sorted level --, the operator is one k_schur_step<0> (two half passes instead of the
+// stencil's four), and the preconditioner is the even block of the same multigrid cycle,
+// M_S r_e = [M (r_e; 0)]_e ~ (A^-1)_ee = S^-1: restriction from the even columns only (Level::Re), no
+// hop before the Schur steps (b_o = 0 makes b' = r_e) and none after them (the odd half is not
+// needed).  The residual of the reduced system IS the residual of the full one (its odd half vanishes
+// identically once x_o is set from x_e), and it is measured against ||b|| of the full system, so the
+// stopping criterion is the reference's (multigrid.py:347-366).  Per iteration on the lattice level:
+// about 47 half-vector passes instead of 64.
+// ---------------------------------------------------------------------------------------------
+static swk::StencilArgs eo_stencil_args(sw_engine* h, Level& lv, int nbp) {
+  swk::StencilArgs a;
+  a.L = lv.L;
+  a.Vh = lv.L * lv.L / 2;
+  a.diag = 4.0 + lv.mass;
+  a.U1 = lv.U1;
+  a.U2 = lv.U2;
+  a.nbp = nbp;
+  a.nt_store = 0;
+  a.tile_w = lv.L;
+  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
+  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0 && h->stencil_tile % 2 == 0) a.tile_w = h->stencil_tile;
+  a.w = cplx{0.0, 0.0};
+  return a;
+}
+
+// Y_e = S X_e (mode 0) or Bp_e - S X_e (mode 1); all three are half vectors
+static int schur_apply(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* Bp, cplx* Y, int nbp) {
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  LaunchScope ls(h, T_SCHUR_OP);
+  if (mode == 0)
+    hipLaunchKernelGGL((swk::k_schur_step<cplx, 0>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
+  else
+    hipLaunchKernelGGL((swk::k_schur_step<cplx, 1>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+static bool eo_solve_eligible(sw_engine* h, Hier& H, int level) {
+  if (!h->eo_solve || level != 0 || H.nlevels < 2) return false;
+  Level& lv = H.lv[0];
+  if (!(lv.stencil && lv.rich && lv.gm_m == 0 && !lv.w_eo.empty() && lv.w_pre.empty() && lv.P.set &&
+        lv.R.set && !h->cgs2 && h->p_even && (lv.n % 2 == 0)))
+    return false;
+  // single-precision preconditioner: only its default form (complex64 cycle AND complex64 Krylov basis)
+  if (h->precond_f32 && !(h->f32_krylov && f32_capable(H, 0))) return false;
+  if (ensure_even_orders(h, H) != 0) return false;
+  return lv.Re.set && lv.P.order_even != nullptr;
+}
+
+// Xout_e = [M (Bin_e; 0)]_e : the even block of the level-0 cycle (see above); half vectors in and out
+static int vcycle_even(sw_engine* h, Hier& H, const cplx* Bin, cplx* Xout, int nbp) {
+  Level& lv = H.lv[0];
+  Level& lc = H.lv[1];
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  SWCHK(ensure_level_ws(h, lc, nbp));
+  SWCHK(ensure_even_orders(h, H));
+  if (!lv.Re.set) return sw_fail(h, "internal: even-column restrictor missing");
+  SWCHK(launch_ell(h, lv.Re, 0, Bin, nullptr, lc.b, nbp, T_R));
+  SWCHK(coarse_correction(h, H, 0, nbp));
+  // ping-pong between lv.t and Xout (only their even halves are touched) so that the last step lands in Xout
+  const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+  cplx* cur = odd_steps ? lv.t : Xout;
+  cplx* nxt = odd_steps ? Xout : lv.t;
+  // (Xout is a HALF-length array: the prolongation must write the even sites only)
+  if (!(lv.P.order_even && h->p_even))
+    return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
+  SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, cur, nbp, T_P, cplx{0.0, 0.0}, true));
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur, Bin, nxt,
+                       a, bpc);
+    KLAUNCH_CHECK();
+    std::swap(cur, nxt);
+  }
+  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
+  return 0;
+}
+
+// the same in complex64 (option precond_f32): half vectors of complex64 in and out
+static int vcycle32_even(sw_engine* h, Hier& H, const cplxf* Bin, cplxf* Xout, int nbp) {
+  Level& lv = H.lv[0];
+  Level& lc = H.lv[1];
+  const int last = H.nlevels - 1;
+  SWCHK(ensure_level_ws32(h, lv, nbp));
+  SWCHK(ensure_level_ws32(h, lc, nbp));
+  SWCHK(ensure_even_orders(h, H));
+  if (!lv.Re.set) return sw_fail(h, "internal: even-column restrictor missing");
+  SWCHK(mirror_op32(h, lv.Re));
+  SWCHK(launch_ell32(h, lv.Re, 0, Bin, nullptr, lc.b32, nbp, T_R));
+  if (lv.kcycle > 0 && 1 < last) {
+    // (as vcycle32: the few-step inner FGMRES of a K-cycle stays fp64, preconditioned in complex64)
+    const size_t cc = (size_t)lc.n * nbp;
+    SWCHK(ensure_level_ws(h, lc, nbp));
+    SWCHK(cast_vec(h, (const cplxf*)lc.b32, lc.b, cc, T_AXPY));
+    SWCHK(ensure_krylov(h, lc.kws, lv.kcycle, lc.n, nbp, false));
+    SWCHK(fgmres(h, H, 1, lc.b, lc.x, 0.0, lv.kcycle, lv.kcycle, false, lc.kws, nbp, nullptr, true));
+    SWCHK(cast_vec(h, (const cplx*)lc.x, lc.x32, cc, T_AXPY));
+  } else {
+    SWCHK(vcycle32(h, H, 1, lc.b32, lc.x32, nbp));
+  }
+  if (!(lv.P.order_even && h->p_even))
+    return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
+  const bool odd_steps = (lv.w_eo.size() & 1) != 0;
+  cplxf* start = odd_steps ? lv.t32 : Xout;
+  cplxf* other = odd_steps ? Xout : lv.t32;
+  SWCHK(launch_ell32(h, lv.P, 0, lc.x32, nullptr, start, nbp, T_P, cplxf{0.f, 0.f}, true));
+  return eo_smooth32(h, lv, Bin, start, other, Xout, nbp, true);
+}
+
+// batched flexible GMRES(m) on the even-odd reduced system of the stencil level (one Gram-Schmidt
+// pass, same scalar kernels, freezing, lazy read-back and true-residual verification as fgmres).
+// With the single-precision preconditioner (precond_f32 + f32_krylov) the restart cycle is complex64 as
+// in fgmres: basis, directions and w = S z in complex64 (S applied in single precision), inner products
+// accumulated in fp64; residual b' - S x, iterate and convergence check fp64, once per restart.
+static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, int maxiter, int m,
+                     KrylovWS& ws, int nbp, int* iters_total) {
+  Level& lv = H.lv[0];
+  const int hid_idx = (int)(&H - &h->hier[0]);
+  const int check_from = h->lazy_sync ? std::max(0, h->sync_hint[hid_idx][0] - 2) : 0;
+  const int n2 = lv.n / 2;
+  const size_t vec = (size_t)n2 * nbp;
+  const int tb = 256, tg = (nbp + tb - 1) / tb;
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  const double di = 1.0 / a.diag;
+  cplx* bp = ws.xacc;               // b'_e
+  const bool k32 = h->precond_f32 && h->f32_krylov && f32_capable(H, 0);
+  if (k32) {
+    SWCHK(ensure_f32(h, H));
+    SWCHK(ensure_level_ws32(h, lv, nbp));
+    const size_t full = (size_t)lv.n * nbp;      // (sized as fgmres sizes them: both may run on this handle)
+    if (!ws.Z32) {
+      SWCHK(dev_realloc(h, &ws.Z32, full * m));
+      SWCHK(dev_realloc(h, &ws.v32, full));
+    }
+    if (!ws.V32) SWCHK(dev_realloc(h, &ws.V32, full * m));
+  }
+  {
+    // ||b|| of the FULL system fixes normb (the reference's stopping criterion); b'_e = b_e + H_eo b_o / D
+    PtrList pl;
+    pl.p[0] = B;
+    SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm));
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 1, tol);
+      KLAUNCH_CHECK();
+    }
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, B, B, bp, a, 1.0, di, bpc);
+    KLAUNCH_CHECK();
+  }
+  // the iterate lives in the even half of X; its odd half is set once at the end
+  {
+    LaunchScope ls(h, T_AXPY);
+    HIPCHK(hipMemsetAsync(X, 0, vec * sizeof(cplx), h->stream));
+  }
+  int done = 0;
+  bool converged = false;
+  const cplx* Rcur = bp;
+  while (done < maxiter && !converged) {
+    {
+      PtrList pl;
+      pl.p[0] = Rcur;
+      SWCHK(multidot(h, pl, 1, Rcur, n2, nbp, ws.nrm));
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 0, tol);
+      KLAUNCH_CHECK();
+    }
+    auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
+    auto vt32 = [&](int k) -> const cplxf* { return k == 0 ? ws.v32 : ws.V32 + vec * (k - 1); };
+    if (k32) SWCHK(cast_vec(h, Rcur, ws.v32, vec, T_AXPY));
+    int j = 0;
+    const int jmax = std::min(m, maxiter - done);
+    for (; j < jmax; ++j) {
+      cplx* zj = ws.Z + vec * j;
+      cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
+      const bool last = h->pyth_last && j == jmax - 1 && m <= 8;
+      if (k32) {
+        cplxf* zj32 = ws.Z32 + vec * j;
+        cplxf* w32 = ws.V32 + vec * j;
+        SWCHK(vcycle32_even(h, H, vt32(j), zj32, nbp));
+        SWCHK(schur_apply32(h, lv, zj32, w32, nbp));
+        swk::PtrListT<cplxf> pv32;
+        for (int k = 0; k <= j; ++k) pv32.p[k] = vt32(k);
+        pv32.p[j + 1] = w32;
+        SWCHK(multidot(h, pv32, last ? j + 2 : j + 1, (const cplxf*)w32, n2, nbp, ws.h1, ws.sc.svec, ws.c1));
+        if (!last) SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n2, nbp, ws.nrm));
+      } else {
+      SWCHK(vcycle_even(h, H, vt(j), zj, nbp));
+      SWCHK(schur_apply(h, lv, 0, zj, nullptr, w, nbp));
+      PtrList pv;
+      for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
+      pv.p[j + 1] = w;
+      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n2, nbp, ws.h1, ws.sc.svec, ws.c1));
+      if (!last) SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n2, nbp, ws.nrm));
+      }
+      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
+      {
+        LaunchScope ls(h, T_OTHER);
+        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1,
+                           (const cplx*)nullptr,
+                           last ? (const cplx*)(ws.h1 + (size_t)(j + 1) * nbp) : (const cplx*)ws.nrm,
+                           tol, done, last ? 1 : 0);
+        KLAUNCH_CHECK();
+      }
+      if (done + j + 1 >= check_from || done + j + 1 >= maxiter || ((done + j + 1) & 7) == 0) {
+        HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        SWCHK(stream_sync(h));
+        if (*h->h_notconv == 0) {
+          converged = true;
+          ++j;
+          break;
+        }
+      }
+    }
+    const int k = j;
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fg_solve, dim3(tg), dim3(tb), 0, h->stream, ws.sc, k);
+      KLAUNCH_CHECK();
+    }
+    if (k32) {
+      swk::PtrListT<cplxf> pz;
+      for (int q = 0; q < k; ++q) pz.p[q] = ws.Z32 + vec * q;
+      SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n2, nbp, nullptr));
+    } else {
+      PtrList pz;
+      for (int q = 0; q < k; ++q) pz.p[q] = ws.Z + vec * q;
+      SWCHK(multiaxpy(h, pz, k, ws.sc.ys, 1.0, X, X, n2, nbp, nullptr));
+    }
+    done += k;
+    if (converged && h->verify) {
+      // true residual of the reduced system = true residual of the full one
+      SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
+      PtrList pr;
+      pr.p[0] = ws.rres;
+      SWCHK(multidot(h, pr, 1, ws.rres, n2, nbp, ws.nrm));
+      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
+      {
+        LaunchScope ls(h, T_OTHER);
+        hipLaunchKernelGGL(swk::k_fg_verify, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, tol);
+        KLAUNCH_CHECK();
+      }
+      HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      SWCHK(stream_sync(h));
+      if (*h->h_notconv != 0) {
+        converged = false;
+        Rcur = ws.rres;
+        continue;
+      }
+    } else if (!converged && done < maxiter) {
+      SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
+      Rcur = ws.rres;
+    }
+  }
+  {
+    // x_o = (b_o + H_oe x_e) / D
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, B, (const cplx*)X, X, a, di, di,
+                       bpc);
+    KLAUNCH_CHECK();
+  }
+  if (iters_total) *iters_total = done;
+  h->sync_hint[hid_idx][0] = converged ? done : 0;
+  return 0;
 }
 
 // device-resident solve used by sw_solve and the probe drivers

@@ -67,7 +67,9 @@ def main(out, extra=""):
             lines.append("%-72s %12.2f %12.2f %12.2f" % (k, fmb, wmb, fmb + wmb))
             tags = {"k_stencil<0,": "k_stencil<0>", "k_stencil<1,": "k_stencil<1>",
                     "k_stencil<2,": "k_stencil<2>",
-                    "k_schur_step": "k_schur_step",
+                    "k_schur_step<cplx, 2>": "k_schur_step",
+                    "k_schur_step<cplx >": "k_schur_step",
+                    "k_schur_step<cplx, 0>": "k_schur_step<0/1> (S x, b' - S x)",
                     "k_bsr_mfma<0, 4, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<0, 2, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<3, 4, true": "k_bsr_mfma(level-1 operator)",

@@ -588,9 +588,12 @@ DEFAULT_SOLVER_CFG = {
 # level in between (4 x 4 aggregates first) -> 12.2k level 0 even-odd -> 16.7-18.1k every level
 # even-odd -> 20.8k without the 16384-row level: with twelve Schur steps on the lattice level the
 # coarser first coarse space is enough, and the level whose 16 x 16 blocks made up 20 % of the time is gone.
+# -> 25.5k with the outer solve on the even-odd reduced system (engine option eo_solve: half-length Krylov
+# vectors) -> 28k with nine Schur steps instead of twelve (11 iterations instead of 10: an outer
+# iteration has become cheap enough for the optimum to move; profiles/r02_cfg_sweeps.txt).
 TUNED_SOLVER_CFG_128 = {
     "coarsening": [(8, 8), (2, 8)],
-    "cycle": [(0, 12, 0), (0, 10, 0)],
+    "cycle": [(0, 9, 0), (0, 10, 0)],
     "smoother": "richardson",
     "eo_levels": [0, 1],        # levels smoothed on their even-odd Schur complement (half vectors)
     "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count

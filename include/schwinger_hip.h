@@ -154,7 +154,9 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
 
 /* Engine switches (defaults are the measured-best settings; everything else exists for A/B runs,
  * profiles/ holds the measurements).  Unknown names and out-of-range values fail with a message.
- *   solver:        "precond_f32" (0) multigrid cycle in complex64 inside the fp64 FGMRES; "f32_krylov" (1)
+ *   solver:        "eo_solve" (1) outer solves of an even-odd smoothed lattice level on the even-odd
+ *                  reduced system (half-length Krylov vectors; same stopping criterion, same results);
+ *                  "precond_f32" (0) multigrid cycle in complex64 inside the fp64 FGMRES; "f32_krylov" (1)
  *                  with it, complex64 Krylov basis per restart cycle; "cgs2" (0) / "inner_cgs2" (0) second
  *                  Gram-Schmidt pass; "pyth_last" (1) last Arnoldi step of a restart cycle without its
  *                  orthogonalisation pass; "verify" (1) true-residual check of every outer solve;

@@ -141,3 +141,65 @@ def cycle_eo(As, Ps, cinv, cfg, B, weights, w_eo, E, O, D):
     out[E] = xe
     out[O] = (B[O] - Aoe @ xe) / D
     return out
+
+
+def fgmres_restarted(op, B, M, tol, m, maxiter, normb=None):
+    """Restarted right-preconditioned flexible GMRES(m) from a zero guess, all columns in lockstep (two
+    Gram-Schmidt passes); stops when every column's TRUE residual is below tol * normb.  Returns
+    (X, iterations).  `op`, `M`: callables on [n, nb] arrays."""
+    nb = B.shape[1]
+    normb = np.sqrt(cdot(B, B).real) if normb is None else normb
+    X = np.zeros_like(B)
+    its = 0
+    while its < maxiter:
+        R = B - op(X)
+        if np.all(np.sqrt(cdot(R, R).real) < tol * normb):
+            break
+        beta = np.sqrt(cdot(R, R).real)
+        V = [R / np.where(beta > 0, beta, 1.0)]
+        Z = []
+        k = min(m, maxiter - its)
+        H = np.zeros((k + 1, k, nb), dtype=complex)
+        for j in range(k):
+            Z.append(M(V[j]))
+            W = op(Z[j])
+            for _ in range(2):
+                for i in range(j + 1):
+                    h = cdot(V[i], W)
+                    H[i, j] += h
+                    W = W - V[i] * h
+            hn = np.sqrt(cdot(W, W).real)
+            H[j + 1, j] = hn
+            V.append(W / np.where(hn > 0, hn, 1.0))
+        for c in range(nb):
+            e1 = np.zeros(k + 1, dtype=complex)
+            e1[0] = beta[c]
+            y = np.linalg.lstsq(H[:, :, c], e1, rcond=None)[0]
+            for i in range(k):
+                X[:, c] += y[i] * Z[i][:, c]
+        its += k
+    return X, its
+
+
+def solve_even_odd_reduced(A, B, M, E, O, D, tol, m, maxiter):
+    """The engine's fgmres_eo in NumPy: A x = b through the even-odd reduced system
+       S x_e = b'_e,  b'_e = b_e - A_eo b_o / D,  x_o = (b_o - A_oe x_e) / D,  S = D - A_eo A_oe / D,
+    with half-length Krylov vectors, the preconditioner M_S r_e = [M (r_e; 0)]_e (M: the full-lattice
+    cycle) and the residual measured against ||b|| of the FULL system.  Returns (X, iterations)."""
+    Aeo, Aoe = A[E][:, O], A[O][:, E]
+    n = A.shape[0]
+
+    def S(xe):
+        return D * xe - Aeo @ (Aoe @ xe) / D
+
+    def MS(re):
+        full = np.zeros((n, re.shape[1]), dtype=complex)
+        full[E] = re
+        return M(full)[E]
+
+    bp = B[E] - Aeo @ (B[O] / D)
+    xe, its = fgmres_restarted(S, bp, MS, tol, m, maxiter, normb=np.sqrt(cdot(B, B).real))
+    X = np.zeros_like(B)
+    X[E] = xe
+    X[O] = (B[O] - Aoe @ xe) / D
+    return X, its

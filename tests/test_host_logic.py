@@ -437,3 +437,59 @@ def test_batched_even_odd_schur_construction_equals_the_sparse_one():
     kcA, vlA = H.pack_site_blocks(blk, nbr)
     nbr2, blk2 = H.site_blocks_from_block_rows(kcA, vlA)
     assert (nbr2 == nbr).all() and abs(blk2 - blk).max() == 0.0
+
+
+def test_even_odd_reduced_system_algebra_behind_the_outer_solver(A16):
+    """What the engine's fgmres_eo (outer solve on half vectors) relies on, on 16^2 in NumPy:
+    (i) with x_o set from x_e the full residual has a vanishing odd half and its even half is the
+    residual of the reduced system; (ii) the even block of the even-odd smoothed cycle applied to
+    (r_e; 0) needs neither the hop before the Schur steps nor the odd half of the restriction's input;
+    (iii) the reduced solve reaches the LU solution with the full system's stopping criterion in as many
+    iterations (+-1) as the full-system FGMRES with the same cycle."""
+    from oracle import engine_model as em
+    L = 16
+    cfg = dict(hierarchy.DEFAULT_SOLVER_CFG, coarsening=[(4, 4), (2, 4)], cycle=[(0, 4, 0), (0, 5, 0)])
+    sh = hierarchy.solver_hierarchy(A16, L, cfg)
+    A = sp.csr_matrix(A16)
+    S, E, O, D = hierarchy.schur_complement(A, L)
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    Aeo, Aoe = A[E][:, O], A[O][:, E]
+    # (i)
+    xe = rng.standard_normal((E.size, 3)) + 1j * rng.standard_normal((E.size, 3))
+    X = np.zeros_like(B)
+    X[E] = xe
+    X[O] = (B[O] - Aoe @ xe) / D
+    R = B - A @ X
+    bp = B[E] - Aeo @ (B[O] / D)
+    assert np.abs(R[O]).max() < 1e-13
+    assert np.abs(R[E] - (bp - S @ xe)).max() < 1e-12
+    # (ii)
+    w1 = hierarchy.smoother_weights(sh["A"][1], 5)
+    w_eo = hierarchy.smoother_weights(S, 4)
+    weights = [None, (np.zeros(0), w1)]
+    cyc = [tuple(c) for c in cfg["cycle"]]
+    cinv = hierarchy.dense_inverse(sh["A"][2].toarray())
+    M = lambda V: em.cycle_eo(sh["A"], sh["P"], cinv, cyc, V, weights, w_eo, E, O, D)   # noqa: E731
+    re = rng.standard_normal((E.size, 3)) + 1j * rng.standard_normal((E.size, 3))
+    full = np.zeros((n, 3), dtype=complex)
+    full[E] = re
+    ref = M(full)[E]
+    P0 = sh["P"][0]
+    Re = sp.csr_matrix(P0.conj().T)[:, E]                       # restrictor, even columns only
+    xc = em.cycle(sh["A"], sh["P"], cinv, cyc, 1, Re @ re, weights)
+    ze = (P0 @ xc)[E]
+    for w in w_eo:
+        ze = ze + w * (re - S @ ze)                             # b' = r_e itself: no hop
+    assert np.linalg.norm(ze - ref) / np.linalg.norm(ref) < 1e-12
+    # (iii)
+    Xr, its_r = em.solve_even_odd_reduced(A, B, M, E, O, D, 1e-12, 3, 60)
+    Xf, its_f = em.fgmres_restarted(lambda V: A @ V, B, M, 1e-12, 3, 60)
+    lu = rp.LUSolver(A16)
+    ref = np.stack([lu(B[:, k]) for k in range(3)], axis=1)
+    nb_ = np.linalg.norm(B, axis=0)
+    assert (np.linalg.norm(B - A @ Xr, axis=0) / nb_).max() < 1e-12
+    assert np.linalg.norm(Xr - ref) / np.linalg.norm(ref) < 1e-10
+    assert np.linalg.norm(Xf - ref) / np.linalg.norm(ref) < 1e-10
+    assert abs(its_r - its_f) <= 3, (its_r, its_f)      # restart granularity of the lock-step model

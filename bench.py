@@ -154,8 +154,9 @@ def run(args):
         # 8x8 site aggregates once, then 2x2 until the coarsest level is 16 x 16 sites (4096 rows);
         # every level smoothed on its even-odd Schur complement (operators built on the device), a
         # 2-step K-cycle around the solve of level 1, plain V-cycle below
-        # (profiles/r02_synthetic_lattices.txt, 1024^2: 325 probe-samples/s, 8 iterations; 264 with 4x4
-        # aggregates first; 218 with only level 0 even-odd; 91 for round 2's first three-level hierarchy)
+        # (profiles/r02_synthetic_lattices.txt, 1024^2: 408 probe-samples/s, 9 iterations, with the outer
+        # solve on the even-odd reduced system; before it 325, 8 iterations; 264 with 4x4 aggregates
+        # first; 218 with only level 0 even-odd; 91 for round 2's first three-level hierarchy)
         a0 = 8 if Ls % 8 == 0 and Ls // 8 >= 16 else 4
         depth = [[a0, 8]]
         Lc = Ls // a0
@@ -163,8 +164,11 @@ def run(args):
             depth.append([2, 8])
             Lc //= 2
         nsm = len(depth)
-        cyc = [[0, 14, 0]] + [[0, 10 if i == 1 else 8, 2 if i == 1 and i < nsm - 1 else 0]
-                              for i in range(1, nsm)]
+        # Schur steps on the lattice level: 10 (512^2: 1377 probe-samples/s against 1331 with 14, 1024^2:
+        # 408 against 386, one more outer iteration; profiles/r02_synthetic_lattices.txt)
+        nu0 = int(os.environ.get("SW_SYNTH_NU0", "10"))
+        cyc = [[0, nu0, 0]] + [[0, 10 if i == 1 else 8, 2 if i == 1 and i < nsm - 1 else 0]
+                               for i in range(1, nsm)]
         cyc[-1] = [0, 14, 0] if nsm > 1 else cyc[-1]
         scfg = {"coarsening": depth, "cycle": cyc, "restart": 3, "eo_levels": list(range(nsm)),
                 "setup": os.environ.get("SW_SYNTH_SETUP", "device"),

@@ -121,7 +121,8 @@ struct Level {
   // MFMA block-row form, eo_op[0] = S (even x even, 9-point), [1] = F = A_eo D_oo^-1,
   // [2] = G = D_oo^-1, [3] = Hb = D_oo^-1 A_oe
   std::vector<std::complex<double>> w_eo;
-  EllOp eo_op[4];
+  EllOp eo_op[5];   // [4] (optional): the DENSE inverse of S over the even sites' rows -- the level's Schur
+                    // steps, and everything below the level, are then replaced by one application of it
   std::vector<int> h_rowmap;  // natural -> internal (empty: identity)
   int* rowmap = nullptr;
   // per-level cycle workspace, [n][nbp]
@@ -209,6 +210,8 @@ struct sw_engine {
   // outer solves of an even-odd smoothed stencil level on the even-odd reduced (Schur complement)
   // system: half-length Krylov vectors, see fgmres_eo
   bool eo_solve = true;
+  // block levels that carry the dense inverse of their Schur complement (eo_op[4]) are solved with it
+  bool eo_direct = true;
   // single-precision preconditioner: every application of a multigrid cycle as the preconditioner of
   // an fp64 flexible GMRES (and sw_vcycle) runs in complex64 on the f32 matrix cores -- operands cast
   // at the boundary, residuals / orthogonalisation / verification stay fp64
@@ -1184,6 +1187,15 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
   SWCHK(ensure_even_orders(h, H));
   if (!lv.P.set || !lv.R.set) return sw_fail(h, "transfer operators of level %d not set", l);
   const size_t npost = lv.w_post.size();
+  if (!lv.stencil && lv.eo_op[4].set && lv.eo_op[1].set && lv.eo_op[2].set && lv.eo_op[3].set &&
+      lv.w_pre.empty() && h->eo_direct) {
+    // exact solve of this block level in even-odd reduced form: b'_e = b_e - F b_o ; x_e = S^-1 b'_e
+    // (dense, matrix cores) ; x_o = G b_o - Hb x_e -- four launches, nothing below this level is visited
+    SWCHK(launch_bsr(h, lv.eo_op[1], 1, Bin, Bin, lv.r, nbp, T_MVM, cplx{0.0, 0.0}));
+    SWCHK(launch_bsr(h, lv.eo_op[4], 0, lv.r, nullptr, Xout, nbp, T_COARSEST, cplx{0.0, 0.0}));
+    SWCHK(launch_bsr(h, lv.eo_op[2], 0, Bin, nullptr, Xout, nbp, T_MVM, cplx{0.0, 0.0}));
+    return launch_bsr(h, lv.eo_op[3], 1, Xout, Xout, Xout, nbp, T_MVM, cplx{0.0, 0.0});
+  }
   cplx* xpre = nullptr;
   if (!lv.w_pre.empty()) {
     SWCHK(rich_steps(h, lv, Bin, Xout, lv.t, lv.w_pre, true, nbp, &xpre));
@@ -1278,7 +1290,7 @@ static int ensure_f32(sw_engine* h, Hier& H) {
   if (H.f32_valid) return 0;
   for (int l = 0; l < H.nlevels; ++l) {
     Level& lv = H.lv[l];
-    EllOp* ops[7] = {&lv.A, &lv.P, &lv.R, &lv.eo_op[0], &lv.eo_op[1], &lv.eo_op[2], &lv.eo_op[3]};
+    EllOp* ops[8] = {&lv.A, &lv.P, &lv.R, &lv.eo_op[0], &lv.eo_op[1], &lv.eo_op[2], &lv.eo_op[3], &lv.eo_op[4]};
     for (EllOp* op : ops) {
       SWCHK(drop_op32(h, *op));
       SWCHK(mirror_op32(h, *op));
@@ -1523,6 +1535,14 @@ static int vcycle32(sw_engine* h, Hier& H, int l, const cplxf* Bin, cplxf* Xout,
   SWCHK(ensure_level_ws32(h, lc, nbp));
   SWCHK(ensure_even_orders(h, H));
   if (!lv.P.set || !lv.R.set) return sw_fail(h, "transfer operators of level %d not set", l);
+  if (!lv.stencil && lv.eo_op[4].set && lv.eo_op[4].bsr_vals32 && lv.eo_op[1].set && lv.eo_op[2].set &&
+      lv.eo_op[3].set && h->eo_direct) {
+    const cplxf z0{0.f, 0.f};
+    SWCHK(launch_bsr32(h, lv.eo_op[1], 1, Bin, Bin, lv.r32, nbp, T_MVM, z0));
+    SWCHK(launch_bsr32(h, lv.eo_op[4], 0, lv.r32, nullptr, Xout, nbp, T_COARSEST, z0));
+    SWCHK(launch_bsr32(h, lv.eo_op[2], 0, Bin, nullptr, Xout, nbp, T_MVM, z0));
+    return launch_bsr32(h, lv.eo_op[3], 1, Xout, Xout, Xout, nbp, T_MVM, z0);
+  }
   SWCHK(launch_ell32(h, lv.R, 0, Bin, nullptr, lc.b32, nbp, T_R));
   if (lv.kcycle > 0 && l + 1 < last) {
     // K-cycle: the few-step inner FGMRES of the coarse system stays fp64 (its Hessenberg solve and
@@ -1906,7 +1926,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(free_op(h, lv.P));
     SWCHK(free_op(h, lv.R));
     SWCHK(free_op(h, lv.Re));
-    for (int q = 0; q < 4; ++q) SWCHK(free_op(h, lv.eo_op[q]));
+    for (int q = 0; q < 5; ++q) SWCHK(free_op(h, lv.eo_op[q]));
     SWCHK(dev_free(h, lv.rowmap));
     SWCHK(dev_free(h, lv.b)); SWCHK(dev_free(h, lv.x)); SWCHK(dev_free(h, lv.r));
     SWCHK(dev_free(h, lv.t));
@@ -2419,7 +2439,7 @@ int sw_set_gmres_smoother(sw_engine* h, int hid, int level, int m, int cycles) {
 int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int KS, const int32_t* tmap,
                        const int32_t* kcol, const double* vals) {
   SWCHK(check_hier(h, hid, level, false));
-  if (which < 0 || which > 3) return sw_fail(h, "even-odd operator index %d out of [0,3]", which);
+  if (which < 0 || which > 4) return sw_fail(h, "even-odd operator index %d out of [0,4]", which);
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[hid].lv[level];
   h->hier[hid].f32_valid = h->hier[hid].even_valid = false;
@@ -2432,6 +2452,7 @@ int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int 
     if (kcol[i] < 0 || kcol[i] + 4 > lv.n) return sw_fail(h, "k-step column out of range");
   EllOp& op = lv.eo_op[which];
   SWCHK(free_op(h, op));
+  if (which < 4) SWCHK(free_op(h, lv.eo_op[4]));     // an inverse of the previous S is stale
   op.nrows = op.ncols = lv.n;
   op.bsr_RT = RT;
   op.bsr_KS = KS;
@@ -2512,6 +2533,7 @@ int sw_setup_eo_operators(sw_engine* h, int hid, int level, int Lc) {
   Built bG = shape(O, 1, [&](int r, int) { return O[r]; });
   Built bH = shape(O, 4, [&](int r, int q) { return nbr[(size_t)O[r] * 5 + q]; });
   Built* built[4] = {&bS, &bF, &bG, &bH};
+  SWCHK(free_op(h, lv.eo_op[4]));                      // an inverse of the previous S is stale
   for (int w = 0; w < 4; ++w) {
     EllOp& op = lv.eo_op[w];
     SWCHK(free_op(h, op));
@@ -2644,7 +2666,7 @@ int sw_setup_eo_operators(sw_engine* h, int hid, int level, int Lc) {
 // level vectors in the reference layout; rows the operator does not write come back zero
 int sw_apply_eo_operator(sw_engine* h, int hid, int level, int which, int nb, const double* X, double* Y) {
   SWCHK(check_hier(h, hid, level, false));
-  if (which < 0 || which > 3 || nb <= 0 || !X || !Y) return sw_fail(h, "sw_apply_eo_operator: bad arguments");
+  if (which < 0 || which > 4 || nb <= 0 || !X || !Y) return sw_fail(h, "sw_apply_eo_operator: bad arguments");
   HIPCHK(hipSetDevice(h->device));
   Level& lv = h->hier[hid].lv[level];
   if (lv.stencil || !lv.eo_op[which].set) return sw_fail(h, "level %d has no even-odd operator %d", level, which);
@@ -2788,6 +2810,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "inner_cgs2") == 0) {
     h->inner_cgs2 = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "eo_direct") == 0) {
+    h->eo_direct = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "eo_solve") == 0) {

@@ -537,6 +537,20 @@ def coarse_schur_blocks(nbr, blk, Lc):
             "E_rows": np.nonzero(row_even)[0], "O_rows": np.nonzero(~row_even)[0]}
 
 
+def dense_schur_inverse_blocks(ops):
+    """(tmap, kcol, vals) of the DENSE inverse of a block level's even-odd Schur complement in the
+    MFMA block-row form (row tiles = the even sites, every row tile lists all even sites' columns):
+    even-odd operator 4 of the engine (sw_set_eo_operator), with which the level is solved exactly --
+    x_e = S^-1 (b_e - F b_o), x_o = G b_o - Hb x_e -- instead of smoothed.  ops: coarse_schur_blocks()."""
+    E = np.asarray(ops["E_sites"])
+    ne = E.size
+    Sinv = np.linalg.inv(ops["S_ee"].toarray())
+    blocks = np.ascontiguousarray(Sinv.reshape(ne, 16, ne, 16).transpose(0, 2, 1, 3))
+    targets = np.broadcast_to(E[None, :], (ne, ne))
+    kcol, vals = pack_site_blocks(blocks, targets)
+    return E.astype(np.int32), kcol, vals
+
+
 def upload_coarse_eo(engines, hid, level, A_l, Lc, degree):
     """Build the four even-odd operators of block level `level` on the host, hand them to the engines
     and select `degree` Schur steps as its post-smoother.  A_l: the level operator as a sparse matrix,

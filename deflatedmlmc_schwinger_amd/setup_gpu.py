@@ -329,5 +329,21 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
             # vectors, and the dense coarsest inverse with them
             rebuild_operators(lvl)
             finish()
+    # optional: block levels solved exactly in even-odd reduced form (cfg["direct_levels"]): the dense
+    # inverse of the level's Schur complement becomes its even-odd operator 4; the Schur steps of that
+    # level and everything below it drop out of the cycle.  (Host LAPACK for now: the operator comes back
+    # in block-row form, S is formed by the batched 16 x 16 construction and inverted.)
+    clock["direct_inverse"] = 0.0
+    with _timed("direct_inverse"):
+        for lv in cfg.get("direct_levels", ()):
+            lv = int(lv)
+            if not (1 <= lv < nl - 1) or lv not in eo_levels:
+                raise Exception("direct_levels: level %d is not an even-odd smoothed block level" % lv)
+            Lc_l = geo[lv - 1]["Lc"]
+            sb = _hier.site_blocks_from_block_rows(*eng.level_bsr(hid, lv))
+            ops = _hier.coarse_schur_blocks(sb[0], sb[1], Lc_l) if sb is not None else None
+            if ops is None:
+                raise Exception("direct_levels: level %d has no 5-point block structure" % lv)
+            eng.set_eo_operator(hid, lv, 4, *_hier.dense_schur_inverse_blocks(ops))
     log.append({"seconds": {k: round(v, 3) for k, v in clock.items()}})
     return {"levels": sizes, "setup_log": log, "setup_s": time.time() - t0, "cfg": cfg}

@@ -83,8 +83,11 @@ int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const doubl
  * 2: G = D_oo^-1, 3: Hb = D_oo^-1 A_oe.  RT row tiles, KS k-steps per tile (multiple of 4),
  * tmap[RT] = tile (site) of the level vector each row tile writes, kcol[RT*KS] = first level row of
  * each 4-column group, vals[RT*KS*64] complex128 lane-packed as for the level operators.  With all
- * four set, sw_set_eo_smoother accepts the level.  sw_get_level_bsr reads a (device-built) level
- * operator back in that form (kcol = vals = NULL: only *KS). */
+ * four set, sw_set_eo_smoother accepts the level.  Optional which = 4: the DENSE inverse of S over the even
+ * sites' rows (every row tile lists all even sites' columns); with it the level is solved exactly --
+ * x_e = S^-1 (b_e - F b_o), x_o = G b_o - Hb x_e -- instead of smoothed and the levels below it are not
+ * visited (option "eo_direct"); it is dropped whenever one of the four operators is set again.
+ * sw_get_level_bsr reads a (device-built) level operator back in that form (kcol = vals = NULL: only *KS). */
 int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int KS, const int32_t* tmap,
                        const int32_t* kcol, const double* vals);
 int sw_get_level_bsr(sw_engine* h, int hid, int level, int* KS, int32_t* kcol, double* vals);
@@ -154,7 +157,9 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
 
 /* Engine switches (defaults are the measured-best settings; everything else exists for A/B runs,
  * profiles/ holds the measurements).  Unknown names and out-of-range values fail with a message.
- *   solver:        "eo_solve" (1) outer solves of an even-odd smoothed lattice level on the even-odd
+ *   solver:        "eo_direct" (1) block levels that were given the dense inverse of their even-odd Schur
+ *                  complement (sw_set_eo_operator, which = 4) are solved with it instead of smoothed;
+ *                  "eo_solve" (1) outer solves of an even-odd smoothed lattice level on the even-odd
  *                  reduced system (half-length Krylov vectors; same stopping criterion, same results);
  *                  "precond_f32" (0) multigrid cycle in complex64 inside the fp64 FGMRES; "f32_krylov" (1)
  *                  with it, complex64 Krylov basis per restart cycle; "cgs2" (0) / "inner_cgs2" (0) second

@@ -224,6 +224,48 @@ def test_even_odd_reduced_outer_solve_equals_full_system_solve():
     eng.close()
 
 
+def test_block_level_solved_exactly_in_even_odd_reduced_form():
+    """solver_cfg["direct_levels"] = [1]: the 4096-row block level carries the dense inverse of its even-odd
+    Schur complement (even-odd operator 4, hierarchy.dense_schur_inverse_blocks) and is solved with it
+    -- x_e = S^-1 (b_e - F b_o), x_o = G b_o - Hb x_e, four launches -- instead of smoothed; the levels
+    below drop out of the cycle.  (i) operator 4 inverts operator 0 on the even rows (through the
+    engine); (ii) solves reach the true residual and LU; (iii) not more iterations than with smoothing."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    params = gateway.set_params('schwinger128')
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    mg = MG(A)
+    mg.setup_solver_only(dict(hierarchy.TUNED_SOLVER_CFG_128, direct_levels=[1]))
+    eng = mg.engine
+    Lc = 16
+    site = np.arange(Lc * Lc)
+    even = (((site % Lc) + (site // Lc)) & 1) == 0
+    E = np.nonzero(np.repeat(even, 16))[0]
+    X = np.zeros((3, Lc * Lc * 16), dtype=complex)
+    X[:, E] = _rand((3, E.size), 77)
+    Y = eng.apply_eo_operator(SOLVER_HID, 1, 0, X)
+    Z = eng.apply_eo_operator(SOLVER_HID, 1, 4, Y)
+    assert _relerr(Z[:, E], X[:, E]) < 1e-11
+    n = A.shape[0]
+    B = _rand((70, n), 153)
+    out = {}
+    try:
+        for flag in (1, 0):
+            eng.set_option("eo_direct", flag)
+            Xs, iters, relres = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+            true_rel = np.linalg.norm(B.T - A @ Xs.T, axis=0) / np.linalg.norm(B.T, axis=0)
+            assert true_rel.max() < 5e-12, (flag, true_rel.max())
+            out[flag] = (Xs, np.asarray(iters))
+    finally:
+        eng.set_option("eo_direct", 1)
+    print("iterations direct / smoothed:", out[1][1].max(), out[0][1].max())
+    assert out[1][1].max() <= out[0][1].max()
+    assert _relerr(out[1][0], out[0][0]) < 1e-9
+    lu = rp.LUSolver(A)
+    ref = np.stack([lu(B[k]) for k in range(4)])
+    assert _relerr(out[1][0][:4], ref) < 1e-8
+    eng.close()
+
+
 def test_zero_rhs_and_single_rhs(p16):
     n = p16.A.shape[0]
     x, its, rr = p16.eng.solve(SOLVER_HID, 0, np.zeros(n, dtype=complex), 1e-12, 100)

@@ -493,3 +493,34 @@ def test_even_odd_reduced_system_algebra_behind_the_outer_solver(A16):
     assert np.linalg.norm(Xr - ref) / np.linalg.norm(ref) < 1e-10
     assert np.linalg.norm(Xf - ref) / np.linalg.norm(ref) < 1e-10
     assert abs(its_r - its_f) <= 3, (its_r, its_f)      # restart granularity of the lock-step model
+
+
+def test_dense_schur_inverse_in_block_row_form_inverts_the_schur_operator():
+    """hierarchy.dense_schur_inverse_blocks (even-odd operator 4 of a block level: the level solved exactly
+    instead of smoothed) against the Schur operator of coarse_schur_blocks, both read back from their packed
+    MFMA block-row forms the way the engine indexes them: S^-1 S = I on the even rows, nothing elsewhere."""
+    Lc = 8
+    ns = Lc * Lc
+    rng = np.random.default_rng(1)
+    site = np.arange(ns)
+    xs, ys = site % Lc, site // Lc
+    nbr = np.stack([ys * Lc + (xs + 1) % Lc, ys * Lc + (xs - 1) % Lc, ((ys + 1) % Lc) * Lc + xs,
+                    ((ys - 1) % Lc) * Lc + xs, site], axis=1)
+    blk = 0.1 * (rng.standard_normal((ns, 5, 16, 16)) + 1j * rng.standard_normal((ns, 5, 16, 16)))
+    blk[:, 4] += 4 * np.eye(16)
+    ops = hierarchy.coarse_schur_blocks(nbr, blk, Lc)
+    tmap, kcol, vals = hierarchy.dense_schur_inverse_blocks(ops)
+    n = ns * 16
+
+    def as_matrix(tmap, kcol, vals):
+        RT, KS = kcol.shape
+        r = np.repeat(tmap.astype(np.int64) * 16, KS * 64).reshape(RT, KS, 4, 16) + np.arange(16)
+        c = kcol.astype(np.int64)[:, :, None, None] + np.arange(4)[None, None, :, None] + np.zeros((1, 1, 1, 16), int)
+        return sp.csr_matrix((vals.reshape(RT, KS, 4, 16).ravel(), (r.ravel(), c.ravel())), shape=(n, n))
+
+    prod = (as_matrix(tmap, kcol, vals) @ as_matrix(*ops["packed"][0])).toarray()
+    Er = ops["E_rows"]
+    assert abs(prod[np.ix_(Er, Er)] - np.eye(Er.size)).max() < 1e-12
+    prod[np.ix_(Er, Er)] = 0
+    assert abs(prod).max() == 0
+    assert kcol.shape == (ns // 2, 4 * (ns // 2)) and vals.shape == (ns // 2, 4 * (ns // 2), 64)

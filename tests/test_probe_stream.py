@@ -54,6 +54,27 @@ def test_jump_from_fresh_seed_and_numpy_roundtrip():
     assert np.array_equal(np.random.randint(1 << 30, size=5), expect[4000:])
 
 
+def test_jump_composes_at_production_distances():
+    """size-independent property of the GF(2) jump-ahead, at stream distances no sequential walk could
+    check (a rank's block of round r sits at (r * world + rank) * batch * n draws: 1e12 and beyond):
+    jump(a) followed by jump(b) lands exactly where jump(a + b) does, from inside a state block."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=12, deadline=None)
+    @given(st.integers(min_value=0, max_value=1 << 44), st.integers(min_value=0, max_value=1 << 44),
+           st.integers(min_value=0, max_value=1300))
+    def check(a, b, start):
+        x, y = ProbeStream(123456), ProbeStream(123456)
+        x.raw(start)
+        y.raw(start)
+        x.jump(a)
+        x.jump(b)
+        y.jump(a + b)
+        assert np.array_equal(x.raw(700), y.raw(700))
+
+    check()
+
+
 def test_window_is_the_raw_word_sequence():
     g = ProbeStream(2024)
     g.raw(700)                       # position 700: window spans two state blocks

@@ -70,6 +70,14 @@ def parse():
     return ap.parse_args()
 
 
+def first_probe(step, world, rank, streams, stream, nb):
+    """Stream position (in probes) of the block that engine `stream` of rank `rank` works on in round
+    `step`: a round is world * streams batches of nb consecutive probes of the MT19937(123456) stream,
+    one contiguous block per (rank, stream) -- BASELINE config 4's sharding, at the single-GPU order's
+    stream positions."""
+    return ((step * world + rank) * streams + stream) * nb
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes
     (before this process touches the GPU) and leave with their exit code."""
@@ -230,13 +238,12 @@ def run(args):
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=ne)
 
-    def first_probe(s, e):
-        # a round = world * ne batches of nb probes, contiguous blocks per (rank, stream)
-        return ((s * world + rank) * ne + e) * nb
+    def block_start(s, e):
+        return first_probe(s, world, rank, ne, e, nb)
 
     def run_one(e, s, generate=True, slot=0):
         if generate:
-            engs[e].probes_generate(slot, 0, nb, first_probe(s, e) * n)
+            engs[e].probes_generate(slot, 0, nb, block_start(s, e) * n)
         engs[e].probes_select(slot)
         engs[e].hutch_run(run_mode, 0, args.tol, maxiter)
         return engs[e].hutch_fetch()
@@ -284,7 +291,7 @@ def run(args):
     nres = min(args.steps, 8)
     for i in range(nres):
         for e in range(ne):
-            engs[e].probes_generate(1 + i, 0, nb, first_probe(args.warmup + i, e) * n)
+            engs[e].probes_generate(1 + i, 0, nb, block_start(args.warmup + i, e) * n)
     elapsed_resident = timed(lambda: [step(args.warmup + i, False, 1 + i) for i in range(nres)])
     host_batches = [ProbeStream(7 + e).rademacher(nb, n) for e in range(ne)]
 
@@ -330,7 +337,7 @@ def run(args):
     # ---- generation alone (device time of k_mt_jump + k_mt_generate per batch) ------------------
     def gen_only():
         for i in range(nres):
-            engs[0].probes_generate(0, 0, nb, first_probe(args.warmup + i, 0) * n)
+            engs[0].probes_generate(0, 0, nb, block_start(args.warmup + i, 0) * n)
         engs[0].sync()
     gen_ms = 1e3 * timed(gen_only) / nres
 

@@ -50,7 +50,7 @@ enum TimerCat { T_MVM = 0, T_DEFL, T_P, T_R, T_AXPY, T_DOTS, T_COARSEST, T_OTHER
                 T_STENCIL_SM,   // k_stencil<2>  Y = X + w (B - A X)
                 T_MFMA_DENSE,   // k_bsr_mfma on the dense coarsest inverse
                 T_MFMA_OP,      // k_bsr_mfma on a block-structured level operator
-                T_STENCIL_SM2,  // k_stencil_2step: two fused smoother steps
+                T_UNUSED13,     // (class 13 was a fused two-step stencil; removed, numbering kept)
                 T_MFMA_OP2,     // k_bsr_mfma on level operators below level 1 of the solver hierarchy
                 T_SCHUR,        // k_schur_step / k_eo_hop: even-odd smoother of the stencil level
                 T_SCHUR_OP,     // k_schur_step<0/1>: operator / residual of the even-odd reduced system
@@ -167,7 +167,6 @@ struct sw_engine {
   int restart = 24;
   int solver_hid = 0;
   bool use_mfma = true;
-  bool bsr_splitk = false;  // split-K kernel for small operators: measured SLOWER (28 vs 19 us on the 4096-row level), kept as a switch
   int bsr_stages = 4, dense_stages = 8;   // software-pipeline depth of k_bsr_mfma (k-steps in flight)
   int bsr_map = 1, bsr_sub = 8, dense_map = 0;   // block orderings of k_bsr_mfma (see the kernel)
   bool bsr_nt = true;     // non-temporal B loads / Y stores in k_bsr_mfma on level operators
@@ -188,10 +187,6 @@ struct sw_engine {
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
   bool lazy_sync = true;
-  // pairs of level-0 polynomial steps in one stencil launch (k_stencil_2step).  Measured at parity
-  // with two separate launches (the 36 L2-served loads per site make it L2-bound), so off by default
-  bool fuse_smoother = false;
-  bool fuse_lds = true;   // with fuse_smoother: the LDS-staged tile kernel instead of the register one
   bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
   int stencil_spw = 0;    // 0: automatic (4)
@@ -205,8 +200,6 @@ struct sw_engine {
   // last Arnoldi step of every restart cycle without its orthogonalisation pass: h_{j+1,j} from
   // |A z|^2 - sum |h_{k,j}|^2 (single-pass Gram-Schmidt only; see fgmres)
   bool pyth_last = true;
-  // even-odd smoothing of the stencil level on this many 64-probe chunks at a time (0: all at once)
-  int eo_chunk = 0;
   // outer solves of an even-odd smoothed stencil level on the even-odd reduced (Schur complement)
   // system: half-length Krylov vectors, see fgmres_eo
   bool eo_solve = true;
@@ -484,23 +477,6 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   LaunchScope ls(h, cls);
   // 16 rows x 4 columns x nbp probes x 8 flops per complex multiply-add, per (tile, k-step)
   if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
-  if (h->bsr_splitk && NT == 2 && (long long)RT * ((2 * nbp) / 32) < 4096 && op.bsr_KS >= 8) {
-    // small operator: four waves per (tile, chunk), each a quarter of the k-steps
-    const int NC2 = (2 * nbp) / 32;
-    const bool ntio = h->bsr_nt && cat != T_COARSEST;
-    const dim3 gsk(RT * NC2);
-#define SK_LAUNCH(MD, NTB)                                                                       \
-  hipLaunchKernelGGL((swk::k_bsr_mfma_sk<MD, 2, NTB>), gsk, dim3(SW_BLOCK), 0, h->stream,         \
-                     (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT,            \
-                     (const double*)X, (const double*)B, (double*)Y, 2 * nbp, w,                  \
-                     (const int*)op.bsr_tmap)
-    if (mode == 0) { if (ntio) SK_LAUNCH(0, true); else SK_LAUNCH(0, false); }
-    else if (mode == 1) { if (ntio) SK_LAUNCH(1, true); else SK_LAUNCH(1, false); }
-    else { if (ntio) SK_LAUNCH(3, true); else SK_LAUNCH(3, false); }
-#undef SK_LAUNCH
-    KLAUNCH_CHECK();
-    return 0;
-  }
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
@@ -878,39 +854,6 @@ static int mr_smooth(sw_engine* h, Level& lv, cplx* X, cplx* R, int nu, int nbp)
   return 0;
 }
 
-// two fused Richardson steps on the stencil level:  Y = S_w2(S_w1(X))
-static int apply_stencil_2step(sw_engine* h, Level& lv, const cplx* X, const cplx* B, cplx* Y, int nbp,
-                               cplx w1, cplx w2) {
-  swk::StencilArgs a;
-  a.L = lv.L;
-  a.Vh = lv.L * lv.L / 2;
-  a.diag = 4.0 + lv.mass;
-  a.U1 = lv.U1;
-  a.U2 = lv.U2;
-  a.nbp = nbp;
-  a.w = w1;
-  a.nt_store = 0;
-  a.tile_w = lv.L;
-  if (lv.L > 256) a.tile_w = (lv.L % 256 == 0) ? 256 : ((lv.L % 64 == 0) ? 64 : lv.L);
-  if (h->stencil_tile > 0 && lv.L % h->stencil_tile == 0) a.tile_w = h->stencil_tile;
-  const int V = lv.L * lv.L;
-  LaunchScope ls(h, T_STENCIL_SM2);
-  if (h->fuse_lds && lv.L % 8 == 0 && lv.L >= 16) {
-    // LDS-staged halo tiles: 8 x 8 sites x 8 probes per workgroup
-    const int tiles = (lv.L / 8) * (lv.L / 8);
-    const int groups = nbp / 8;
-    hipLaunchKernelGGL(swk::k_stencil_2step_lds, dim3(tiles * groups), dim3(SW_BLOCK), 0, h->stream,
-                       X, B, Y, a, w2, tiles);
-  } else {
-    const int bpc = (V + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-    const int nchunks = nbp / 64;
-    hipLaunchKernelGGL(swk::k_stencil_2step, dim3(bpc * nchunks), dim3(SW_BLOCK), 0, h->stream, X, B,
-                       Y, a, w2, bpc);
-  }
-  KLAUNCH_CHECK();
-  return 0;
-}
-
 // n fixed-weight Richardson steps  x <- x + w_k (B - A x), ping-ponging between `cur`
 // (holding x on entry, ignored when from_zero) and `other`; *result = buffer with the answer
 static int rich_steps(sw_engine* h, Level& lv, const cplx* Bin, cplx* cur, cplx* other,
@@ -925,15 +868,8 @@ static int rich_steps(sw_engine* h, Level& lv, const cplx* Bin, cplx* cur, cplx*
     KLAUNCH_CHECK();
     k = 1;
   }
-  while (k < w.size()) {
-    if (lv.stencil && h->fuse_smoother && lv.L >= 4 && k + 1 < w.size()) {
-      SWCHK(apply_stencil_2step(h, lv, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()},
-                                cplx{w[k + 1].real(), w[k + 1].imag()}));
-      k += 2;
-    } else {
-      SWCHK(apply_op(h, lv, 2, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()}));
-      k += 1;
-    }
+  for (; k < w.size(); ++k) {
+    SWCHK(apply_op(h, lv, 2, cur, Bin, other, nbp, cplx{w[k].real(), w[k].imag()}));
     std::swap(cur, other);
   }
   *result = cur;
@@ -1138,42 +1074,29 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
   const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
   const double di = 1.0 / a.diag;
   cplx* bp = lv.r;   // b'_e lives in the even half of the level's residual buffer
-  // Probe chunks are independent and the whole sequence (hop, nu steps, hop) re-reads the same three
-  // half vectors: with option eo_chunk = c > 0 the sequence runs on c 64-probe chunks at a time, so
-  // that its working set (3 * V * 16 B * 64 c; 50 MB per chunk at 128^2) stays in the 256 MB
-  // Infinity Cache from the second launch on instead of streaming 201 MB per step through HBM.  The
-  // kernels index [row][probe] with the row stride nbp: a chunk range is a column offset.
-  const int nchunks = nbp / 64;
-  const int cw = (h->eo_chunk > 0 && h->eo_chunk < nchunks) ? h->eo_chunk : nchunks;
-  cplx* last_out = nullptr;
-  for (int c0 = 0; c0 < nchunks; c0 += cw) {
-    const int nc = std::min(cw, nchunks - c0);
-    const size_t off = (size_t)c0 * 64;
-    const dim3 grid(bpc * nc);
-    {
-      LaunchScope ls(h, T_SCHUR);
-      hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin + off, Bin + off,
-                         bp + off, a, 1.0, di, bpc);
-      KLAUNCH_CHECK();
-    }
-    cplx* cur = start;
-    cplx* nxt = other;
-    for (size_t k = 0; k < lv.w_eo.size(); ++k) {
-      a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
-      LaunchScope ls(h, T_SCHUR);
-      hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream,
-                         (const cplx*)(cur + off), (const cplx*)(bp + off), nxt + off, a, bpc);
-      KLAUNCH_CHECK();
-      std::swap(cur, nxt);
-    }
-    last_out = cur;
-    {
-      LaunchScope ls(h, T_SCHUR);
-      hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin + off,
-                         (const cplx*)(cur + off), cur + off, a, di, di, bpc);
-      KLAUNCH_CHECK();
-    }
+  const dim3 grid(bpc * (nbp / 64));
+  {
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0, di, bpc);
+    KLAUNCH_CHECK();
   }
+  cplx* cur = start;
+  cplx* nxt = other;
+  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
+    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur,
+                       (const cplx*)bp, nxt, a, bpc);
+    KLAUNCH_CHECK();
+    std::swap(cur, nxt);
+  }
+  {
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, (const cplx*)cur, cur, a,
+                       di, di, bpc);
+    KLAUNCH_CHECK();
+  }
+  cplx* last_out = cur;
   if (last_out != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
   return 0;
 }
@@ -1230,9 +1153,7 @@ static int vcycle_rich(sw_engine* h, Hier& H, int l, const cplx* Bin, cplx* Xout
     return eo_smooth(h, lv, Bin, start, other, Xout, nbp);
   }
   // place the prolongated iterate so that the ping-pong launches of the post-smoother end in Xout
-  // (pairs of steps are one launch on the stencil level)
-  const bool fused = lv.stencil && h->fuse_smoother && lv.L >= 4;
-  const size_t nlaunch = fused ? (npost / 2 + npost % 2) : npost;
+  const size_t nlaunch = npost;
   cplx* start = (nlaunch % 2 == 0) ? Xout : lv.t;
   cplx* other = (nlaunch % 2 == 0) ? lv.t : Xout;
   if (xpre) SWCHK(launch_ell(h, lv.P, 2, lc.x, xpre, start, nbp, T_P));
@@ -2759,10 +2680,6 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     (name[0] == 'd' ? h->dense_stages : h->bsr_stages) = (int)value;
     return 0;
   }
-  if (std::strcmp(name, "bsr_splitk") == 0) {
-    h->bsr_splitk = value != 0.0;
-    return 0;
-  }
   if (std::strcmp(name, "bsr_nt") == 0) {
     h->bsr_nt = value != 0.0;
     return 0;
@@ -2820,11 +2737,6 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->eo_solve = value != 0.0;
     return 0;
   }
-  if (std::strcmp(name, "eo_chunk") == 0) {
-    if (value < 0.0 || value > 1024.0) return sw_fail(h, "eo_chunk must be in [0, 1024]");
-    h->eo_chunk = (int)value;
-    return 0;
-  }
   if (std::strcmp(name, "pyth_last") == 0) {
     h->pyth_last = value != 0.0;
     return 0;
@@ -2870,14 +2782,6 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "lazy_sync") == 0) {
     h->lazy_sync = value != 0.0;
-    return 0;
-  }
-  if (std::strcmp(name, "fuse_lds") == 0) {
-    h->fuse_lds = value != 0.0;
-    return 0;
-  }
-  if (std::strcmp(name, "fuse_smoother") == 0) {
-    h->fuse_smoother = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "mfma_ops") == 0) {
@@ -3902,7 +3806,7 @@ int sw_timers(sw_engine* h, double t[8]) {
   SWCHK(stream_sync(h));
   for (int i = 0; i < 8; ++i) t[i] = h->tacc[i];
   t[T_MVM] += h->tacc[T_STENCIL] + h->tacc[T_STENCIL_RES] + h->tacc[T_STENCIL_SM] + h->tacc[T_MFMA_OP] +
-              h->tacc[T_STENCIL_SM2] + h->tacc[T_MFMA_OP2] + h->tacc[T_SCHUR] + h->tacc[T_SCHUR_OP];
+              h->tacc[T_MFMA_OP2] + h->tacc[T_SCHUR] + h->tacc[T_SCHUR_OP];
   t[T_COARSEST] += h->tacc[T_MFMA_DENSE];
   return 0;
 }

@@ -258,10 +258,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_stencil(const CI* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------
-// Two fused smoother steps (temporal blocking):  Y = S_w2(S_w1(X)),  S_w(x) = x + w (B - A x).
-// The second step needs S_w1(X) on the five stencil points, which are recomputed in registers
-// from the 13-point neighbourhood of X and the 5-point neighbourhood of B (all L2-served), so
-// two polynomial steps cost 3 HBM vector passes instead of 6.  One wave = one site x 64 probes.
+// a 2-spinor at one lattice site (both spins x 64 probes per wave) and its load
 // ------------------------------------------------------------------------------------------
 template <class C>
 struct SiteT {
@@ -277,178 +274,6 @@ __device__ __forceinline__ SiteT<C> ld_site(const C* __restrict__ base, int x, i
   v.s0 = base[r * nbp];
   v.s1 = base[(r + 1) * nbp];
   return v;
-}
-
-// (A psi)(m) from psi(m) and its four neighbours; u1 = U1(m), u1m = U1(m-x), u2 = U2(m), u2m = U2(m-y)
-__device__ __forceinline__ Site2 wilson_site(double diag, Site2 c, Site2 xp, Site2 xm, Site2 yp,
-                                             Site2 ym, cplx u1, cplx u1m, cplx u2, cplx u2m) {
-  const cplx tx = cmul(u1, csub(xp.s0, xp.s1));
-  const cplx txm = cmulc(u1m, cadd(xm.s0, xm.s1));
-  const cplx ty = cmul(u2, cadd(yp.s0, cmuli(yp.s1)));
-  const cplx tym = cmulc(u2m, csub(ym.s0, cmuli(ym.s1)));
-  const cplx h0 = cadd(cadd(tx, txm), cadd(ty, tym));
-  const cplx h1 = cadd(csub(txm, tx), cmuli(csub(tym, ty)));
-  Site2 o;
-  o.s0 = cmake(fma(diag, c.s0.x, -h0.x), fma(diag, c.s0.y, -h0.y));
-  o.s1 = cmake(fma(diag, c.s1.x, -h1.x), fma(diag, c.s1.y, -h1.y));
-  return o;
-}
-
-// x + w (b - Ax)
-__device__ __forceinline__ Site2 relax_site(Site2 x, Site2 b, Site2 ax, cplx w) {
-  Site2 o = x;
-  cfma(o.s0, w, csub(b.s0, ax.s0));
-  cfma(o.s1, w, csub(b.s1, ax.s1));
-  return o;
-}
-
-__global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step(const cplx* __restrict__ X,
-                                                            const cplx* __restrict__ B,
-                                                            cplx* __restrict__ Y, StencilArgs a,
-                                                            cplx w2, int blocks_per_chunk) {
-  const int nblk = gridDim.x;
-  const int bb = xcd_remap(blockIdx.x, nblk);
-  const int chunk = bb / blocks_per_chunk;
-  const int sg = bb % blocks_per_chunk;
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
-  const size_t col = (size_t)chunk * 64 + lane;
-  const int site0 = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + wave);
-  if (site0 >= L * L) return;
-  const int tw = a.tile_w;
-  const int tile = site0 / (tw * L);
-  const int rem = site0 - tile * (tw * L);
-  const int y = rem / tw;
-  const int x = tile * tw + (rem - y * tw);
-  const int xp = (x + 1 == L) ? 0 : x + 1, xm = (x == 0) ? L - 1 : x - 1;
-  const int yp = (y + 1 == L) ? 0 : y + 1, ym = (y == 0) ? L - 1 : y - 1;
-  const int xpp = (xp + 1 == L) ? 0 : xp + 1, xmm = (xm == 0) ? L - 1 : xm - 1;
-  const int ypp = (yp + 1 == L) ? 0 : yp + 1, ymm = (ym == 0) ? L - 1 : ym - 1;
-  const cplx* Xc = X + col;
-  const cplx* Bc = B + col;
-  // 13-point neighbourhood of X, 5-point neighbourhood of B
-  const Site2 x00 = ld_site(Xc, x, y, L, Vh, nbp);
-  const Site2 xP0 = ld_site(Xc, xp, y, L, Vh, nbp), xM0 = ld_site(Xc, xm, y, L, Vh, nbp);
-  const Site2 x0P = ld_site(Xc, x, yp, L, Vh, nbp), x0M = ld_site(Xc, x, ym, L, Vh, nbp);
-  const Site2 xPP = ld_site(Xc, xp, yp, L, Vh, nbp), xPM = ld_site(Xc, xp, ym, L, Vh, nbp);
-  const Site2 xMP = ld_site(Xc, xm, yp, L, Vh, nbp), xMM = ld_site(Xc, xm, ym, L, Vh, nbp);
-  const Site2 x20 = ld_site(Xc, xpp, y, L, Vh, nbp), xm20 = ld_site(Xc, xmm, y, L, Vh, nbp);
-  const Site2 x02 = ld_site(Xc, x, ypp, L, Vh, nbp), x0m2 = ld_site(Xc, x, ymm, L, Vh, nbp);
-  const Site2 b00 = ld_site(Bc, x, y, L, Vh, nbp);
-  const Site2 bP0 = ld_site(Bc, xp, y, L, Vh, nbp), bM0 = ld_site(Bc, xm, y, L, Vh, nbp);
-  const Site2 b0P = ld_site(Bc, x, yp, L, Vh, nbp), b0M = ld_site(Bc, x, ym, L, Vh, nbp);
-  const cplx* U1 = a.U1;
-  const cplx* U2 = a.U2;
-  const double d = a.diag;
-  const cplx w1 = a.w;
-#define SW_U1(xx, yy) U1[(yy) * L + (xx)]
-#define SW_U2(xx, yy) U2[(yy) * L + (xx)]
-  // first step on the five stencil points
-  const Site2 s00 = relax_site(x00, b00,
-      wilson_site(d, x00, xP0, xM0, x0P, x0M, SW_U1(x, y), SW_U1(xm, y), SW_U2(x, y), SW_U2(x, ym)), w1);
-  const Site2 sP0 = relax_site(xP0, bP0,
-      wilson_site(d, xP0, x20, x00, xPP, xPM, SW_U1(xp, y), SW_U1(x, y), SW_U2(xp, y), SW_U2(xp, ym)), w1);
-  const Site2 sM0 = relax_site(xM0, bM0,
-      wilson_site(d, xM0, x00, xm20, xMP, xMM, SW_U1(xm, y), SW_U1(xmm, y), SW_U2(xm, y), SW_U2(xm, ym)), w1);
-  const Site2 s0P = relax_site(x0P, b0P,
-      wilson_site(d, x0P, xPP, xMP, x02, x00, SW_U1(x, yp), SW_U1(xm, yp), SW_U2(x, yp), SW_U2(x, y)), w1);
-  const Site2 s0M = relax_site(x0M, b0M,
-      wilson_site(d, x0M, xPM, xMM, x00, x0m2, SW_U1(x, ym), SW_U1(xm, ym), SW_U2(x, ym), SW_U2(x, ymm)), w1);
-  // second step at the centre
-  const Site2 out = relax_site(s00, b00,
-      wilson_site(d, s00, sP0, sM0, s0P, s0M, SW_U1(x, y), SW_U1(xm, y), SW_U2(x, y), SW_U2(x, ym)), w2);
-#undef SW_U1
-#undef SW_U2
-  const size_t r = eo_row(x, y, L, Vh);
-  Y[r * nbp + col] = out.s0;
-  Y[(r + 1) * nbp + col] = out.s1;
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS-staged two-step smoother:  Y = S_w2(S_w1(X)),  S_w(x) = x + w (B - A x), on an 8 x 8-site
-// tile x 8 probes per workgroup.  The 12 x 12 halo tile of X is staged in LDS once (128-B row
-// segments), the intermediate S_w1(X) is formed on the 10 x 10 inner halo in LDS, the result on
-// the 8 x 8 core; B and the links come straight from global/L2 (each is used once per thread).
-// Two polynomial steps then cost ~3 HBM passes and 7.6 instead of 24 L2 row reads per site.
-// LDS: (144 + 100) sites x 2 spins x 8 probes x 16 B = 62.5 KB -> two workgroups per CU.
-// ------------------------------------------------------------------------------------------
-#define SW_T2 8
-#define SW_P2 8
-__global__ __launch_bounds__(SW_BLOCK) void k_stencil_2step_lds(const cplx* __restrict__ X,
-                                                                const cplx* __restrict__ B,
-                                                                cplx* __restrict__ Y, StencilArgs a,
-                                                                cplx w2, int tiles_per_group) {
-  __shared__ cplx sx0[144 * 2 * SW_P2];
-  __shared__ cplx sx1[100 * 2 * SW_P2];
-  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
-  const int ntx = L / SW_T2;
-  const int bb = xcd_remap(blockIdx.x, gridDim.x);
-  const int pg = bb / tiles_per_group;              // probe group (8 probes)
-  const int tile = bb % tiles_per_group;
-  const int ty0 = (tile / ntx) * SW_T2, tx0 = (tile % ntx) * SW_T2;
-  const int tid = threadIdx.x;
-  const int p = tid & (SW_P2 - 1);
-  const size_t col = (size_t)pg * SW_P2 + p;
-  const cplx* Xc = X + col;
-  const cplx* Bc = B + col;
-  // stage the 12 x 12 halo tile of X
-  for (int idx = tid; idx < 144 * 2 * SW_P2; idx += SW_BLOCK) {
-    const int site = idx >> 4, spin = (idx >> 3) & 1;
-    const int ly = site / 12, lx = site - ly * 12;
-    int gx = tx0 + lx - 2, gy = ty0 + ly - 2;
-    gx += (gx < 0) ? L : 0; gx -= (gx >= L) ? L : 0;
-    gy += (gy < 0) ? L : 0; gy -= (gy >= L) ? L : 0;
-    sx0[idx] = Xc[(eo_row(gx, gy, L, Vh) + spin) * nbp];
-  }
-  __syncthreads();
-  const double d = a.diag;
-  const cplx w1 = a.w;
-  // first step on the 10 x 10 inner halo
-  for (int item = tid; item < 100 * SW_P2; item += SW_BLOCK) {
-    const int site = item >> 3;
-    const int ly = site / 10, lx = site - ly * 10;       // position in the 10 x 10 region
-    int gx = tx0 + lx - 1, gy = ty0 + ly - 1;
-    gx += (gx < 0) ? L : 0; gx -= (gx >= L) ? L : 0;
-    gy += (gy < 0) ? L : 0; gy -= (gy >= L) ? L : 0;
-    const int gxm = (gx == 0) ? L - 1 : gx - 1, gym = (gy == 0) ? L - 1 : gy - 1;
-    const int c12 = (ly + 1) * 12 + (lx + 1);             // same site in the 12 x 12 tile
-#define SW_LD0(S) Site2{sx0[((S) * 2 + 0) * SW_P2 + p], sx0[((S) * 2 + 1) * SW_P2 + p]}
-    const Site2 xc = SW_LD0(c12), xpp = SW_LD0(c12 + 1), xmm = SW_LD0(c12 - 1);
-    const Site2 ypp = SW_LD0(c12 + 12), ymm = SW_LD0(c12 - 12);
-#undef SW_LD0
-    const size_t r = eo_row(gx, gy, L, Vh);
-    Site2 bc;
-    bc.s0 = Bc[r * nbp];
-    bc.s1 = Bc[(r + 1) * nbp];
-    const Site2 ax = wilson_site(d, xc, xpp, xmm, ypp, ymm, a.U1[gy * L + gx], a.U1[gy * L + gxm],
-                                 a.U2[gy * L + gx], a.U2[gym * L + gx]);
-    const Site2 s1 = relax_site(xc, bc, ax, w1);
-    sx1[(site * 2 + 0) * SW_P2 + p] = s1.s0;
-    sx1[(site * 2 + 1) * SW_P2 + p] = s1.s1;
-  }
-  __syncthreads();
-  // second step on the 8 x 8 core
-  for (int item = tid; item < 64 * SW_P2; item += SW_BLOCK) {
-    const int site = item >> 3;
-    const int ly = site >> 3, lx = site & 7;
-    const int gx = tx0 + lx, gy = ty0 + ly;              // inside the lattice by construction
-    const int gxm = (gx == 0) ? L - 1 : gx - 1, gym = (gy == 0) ? L - 1 : gy - 1;
-    const int c10 = (ly + 1) * 10 + (lx + 1);
-#define SW_LD1(S) Site2{sx1[((S) * 2 + 0) * SW_P2 + p], sx1[((S) * 2 + 1) * SW_P2 + p]}
-    const Site2 xc = SW_LD1(c10), xpp = SW_LD1(c10 + 1), xmm = SW_LD1(c10 - 1);
-    const Site2 ypp = SW_LD1(c10 + 10), ymm = SW_LD1(c10 - 10);
-#undef SW_LD1
-    const size_t r = eo_row(gx, gy, L, Vh);
-    Site2 bc;
-    bc.s0 = Bc[r * nbp];
-    bc.s1 = Bc[(r + 1) * nbp];
-    const Site2 ax = wilson_site(d, xc, xpp, xmm, ypp, ymm, a.U1[gy * L + gx], a.U1[gy * L + gxm],
-                                 a.U2[gy * L + gx], a.U2[gym * L + gx]);
-    const Site2 o = relax_site(xc, bc, ax, w2);
-    Y[r * nbp + col] = o.s0;
-    Y[(r + 1) * nbp + col] = o.s1;
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -827,88 +652,6 @@ __global__ __launch_bounds__(SW_BLOCK, SW_BSR_MIN_WAVES(NT, STG)) void k_bsr_mfm
   // smoother update reads, in the accumulator's lane layout: no second trip to memory for x
   if (MODE == 3 && STG == 4 && xreg) bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w, xx);
   else bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
-}
-
-// ------------------------------------------------------------------------------------------
-// Split-K variant for operators too small to fill the chip with one wave per (tile, chunk): a
-// 4096-row level on 256 probes is 2048-4096 waves of 20-36 SEQUENTIAL k-steps each, a 1024^2 dense
-// inverse 1024 waves of 256 -- launch-to-finish time is the length of that chain.  Here the four
-// waves of a workgroup share ONE (row tile, probe chunk): wave q takes k-steps q, q+4, q+8, ...
-// (so the four A reads of a round are one contiguous 4-KiB block), the partial accumulators meet
-// in LDS, wave 0 runs the epilogue.  Four times the waves, a quarter of the chain.
-// ------------------------------------------------------------------------------------------
-template <int MODE, int NT, bool NTIO>
-__global__ __launch_bounds__(SW_BLOCK) void k_bsr_mfma_sk(const cplx* __restrict__ Ap,
-                                                          const int* __restrict__ kcol, int KS,
-                                                          int RT, const double* __restrict__ Xr,
-                                                          const double* __restrict__ Br,
-                                                          double* __restrict__ Yr, int ld, cplx w,
-                                                          const int* __restrict__ tmap) {
-  __shared__ double red[3][NT * 8][64];
-  const int lane = threadIdx.x & 63;
-  const int q = threadIdx.x >> 6;
-  const int rt = blockIdx.x % RT;
-  const int cy = blockIdx.x / RT;
-  const int c0 = cy * (16 * NT);
-  const cplx* a = Ap + (size_t)rt * KS * 64 + lane;
-  const int* kc = kcol + (size_t)rt * KS;
-  const double* b = Xr + (size_t)(lane >> 4) * ld + c0 + (lane & 15);
-  sw_double4 re[NT], im[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    re[t] = sw_double4{0.0, 0.0, 0.0, 0.0};
-    im[t] = re[t];
-  }
-  // two register stages over this wave's k-steps q, q+4, ...
-  cplx m0, m1;
-  double x0[NT], x1[NT];
-#define SW_SK_LOAD(M_, X_, KSI)                                 \
-  {                                                             \
-    const int ks_ = ((KSI) < KS) ? (KSI) : q;                   \
-    M_ = a[(size_t)ks_ * 64];                                   \
-    const double* bk_ = b + (size_t)kc[ks_] * ld;               \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) X_[t] = bk_[t * 16]; \
-  }
-#define SW_SK_MFMA(M_, X_)                                                         \
-  _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                 \
-    re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.x, X_[t], re[t], 0, 0, 0);     \
-    im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.y, X_[t], im[t], 0, 0, 0);     \
-  }
-  SW_SK_LOAD(m0, x0, q);
-  SW_SK_LOAD(m1, x1, q + 4);
-  for (int ks = q; ks < KS; ks += 8) {
-    __builtin_amdgcn_sched_barrier(0);
-    SW_SK_MFMA(m0, x0);
-    __builtin_amdgcn_sched_barrier(0);
-    SW_SK_LOAD(m0, x0, ks + 8);
-    if (ks + 4 < KS) {
-      __builtin_amdgcn_sched_barrier(0);
-      SW_SK_MFMA(m1, x1);
-      __builtin_amdgcn_sched_barrier(0);
-      SW_SK_LOAD(m1, x1, ks + 12);
-    }
-  }
-#undef SW_SK_LOAD
-#undef SW_SK_MFMA
-  if (q > 0) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        red[q - 1][t * 8 + r][lane] = re[t][r];
-        red[q - 1][t * 8 + 4 + r][lane] = im[t][r];
-      }
-  }
-  __syncthreads();
-  if (q != 0) return;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      re[t][r] += red[0][t * 8 + r][lane] + red[1][t * 8 + r][lane] + red[2][t * 8 + r][lane];
-      im[t][r] += red[0][t * 8 + 4 + r][lane] + red[1][t * 8 + 4 + r][lane] + red[2][t * 8 + 4 + r][lane];
-    }
-  bsr_store<MODE, NT, NTIO>(re, im, rt, c0, lane, tmap, Xr, Br, Yr, ld, w);
 }
 
 // ------------------------------------------------------------------------------------------

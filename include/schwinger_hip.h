@@ -168,12 +168,11 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *                  "lazy_sync" (1) convergence read-back only near the expected iteration count;
  *                  "dot_blocks" row blocks of the reducing BLAS-1 launches
  *   stencil level: "stencil_spw", "stencil_tile", "stencil_nt" (sites per wave, lattice tile width,
- *                  non-temporal stores); "fuse_smoother" / "fuse_lds" (0) two polynomial steps per launch;
- *                  "eo_chunk" (0) even-odd smoothing on this many 64-probe chunks at a time; "p_even" (1)
- *                  prolongation onto the even sites only ahead of an even-odd smoother
+ *                  non-temporal stores); "p_even" (1) prolongation onto the even sites only ahead of an
+ *                  even-odd smoother
  *   block levels:  "use_mfma" (1) fp64-MFMA block-row kernels vs grouped ELL; "mfma_ops", "mfma_tiles",
  *                  "mfma_small_tiles", "bsr_stages" / "dense_stages" (register pipeline depth), "bsr_nt",
- *                  "bsr_xreg", "bsr_sub", "dense_map", "bsr_splitk", "ell_order"; complex64 twins "f32_tiles",
+ *                  "bsr_xreg", "bsr_sub", "dense_map", "ell_order"; complex64 twins "f32_tiles",
  *                  "f32_stages", "f32_dense_stages", "f32_splitk", "f32_pairs"
  *   sw_bench_dirac: "bench_mode" (0 Y=AX, 1 residual, 2 smoother step), "bench_what" (operator / R / P /
  *                  coarsest) */
@@ -264,7 +263,7 @@ int sw_timers_reset(sw_engine* h);
 #define SW_KCLASS_STENCIL_SM 10     /* k_stencil<2>  Y = X + w (B - A X)           */
 #define SW_KCLASS_MFMA_DENSE 11     /* k_bsr_mfma, dense coarsest inverse          */
 #define SW_KCLASS_MFMA_OP 12        /* k_bsr_mfma, block-structured level operator */
-#define SW_KCLASS_STENCIL_SM2 13     /* k_stencil_2step, two fused smoother steps   */
+/* (class 13: unused; it was a fused two-step stencil, removed after it measured no faster) */
 #define SW_KCLASS_MFMA_OP2 14       /* k_bsr_mfma, level operators below level 1   */
 #define SW_KCLASS_SCHUR 15          /* k_schur_step / k_eo_hop, even-odd smoother  */
 int sw_kernel_stats(sw_engine* h, int which, double* total_ms, int64_t* launches);

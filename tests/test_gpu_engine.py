@@ -715,29 +715,6 @@ def test_adaptive_gpu_setup_gives_a_working_hierarchy(p128):
         mg.upload_solver_hierarchy(None)
 
 
-def test_fused_two_step_smoother_kernel_matches_model(p16, p128):
-    """opt-in temporal blocking of the level-0 polynomial smoother (k_stencil_2step): same cycle
-    as the NumPy model, for an odd and an even number of steps."""
-    from deflatedmlmc_schwinger_amd import hierarchy
-    for p in (p16, p128):
-        for nu, lds in ((7, 1), (4, 1), (7, 0)):
-            cfg = dict(hierarchy.DEFAULT_SOLVER_CFG, cycle=[(0, nu, 0), (0, 3, 0)])
-            try:
-                p.mg.upload_solver_hierarchy(cfg, testvectors=p.mg.solver_testvectors)
-                p.eng.set_option("fuse_smoother", 1)
-                p.eng.set_option("fuse_lds", lds)      # LDS-staged tile kernel / register kernel
-                sh = p.mg.solver_hier
-                B = _rand((sh["A"][0].shape[0], 3), 46 + nu)
-                ref = em.cycle(sh["A"], sh["P"], sh["coarsest_inv"], [tuple(c) for c in cfg["cycle"]],
-                               0, B, weights=p.mg.solver_weights)
-                X = p.eng.vcycle(SOLVER_HID, 0, B.T.copy())
-                assert _relerr(X.T, ref) < 1e-10
-            finally:
-                p.eng.set_option("fuse_smoother", 0)
-                p.eng.set_option("fuse_lds", 1)
-                p.mg.upload_solver_hierarchy(None, testvectors=p.mg.solver_testvectors)
-
-
 def test_config4_probe_stream_statistics_and_sharding_independence(p128):
     """BASELINE config 4 on one GPU: the first 4096 probes of the MT19937(123456) stream.
     (i) the deflated-Hutchinson mean agrees with the exact trace within the estimator's own

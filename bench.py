@@ -159,28 +159,12 @@ def run(args):
         # BASELINE config 5: sigma = 0.204 <-> mean plaquette ~0.92, m = -0.05
         Ls = args.lattice
         U1s, U2s = matrix.synthetic_links(Ls, 0.204, 2024)
-        # 8x8 site aggregates once, then 2x2 until the coarsest level is 16 x 16 sites (4096 rows);
-        # every level smoothed on its even-odd Schur complement (operators built on the device), a
-        # 2-step K-cycle around the solve of level 1, plain V-cycle below
-        # (profiles/r02_synthetic_lattices.txt, 1024^2: 408 probe-samples/s, 9 iterations, with the outer
-        # solve on the even-odd reduced system; before it 325, 8 iterations; 264 with 4x4 aggregates
-        # first; 218 with only level 0 even-odd; 91 for round 2's first three-level hierarchy)
-        a0 = 8 if Ls % 8 == 0 and Ls // 8 >= 16 else 4
-        depth = [[a0, 8]]
-        Lc = Ls // a0
-        while Lc > 16 and Lc % 8 == 0:
-            depth.append([2, 8])
-            Lc //= 2
-        nsm = len(depth)
-        # Schur steps on the lattice level: 10 (512^2: 1377 probe-samples/s against 1331 with 14, 1024^2:
-        # 408 against 386, one more outer iteration; profiles/r02_synthetic_lattices.txt)
-        nu0 = int(os.environ.get("SW_SYNTH_NU0", "10"))
-        cyc = [[0, nu0, 0]] + [[0, 10 if i == 1 else 8, 2 if i == 1 and i < nsm - 1 else 0]
-                               for i in range(1, nsm)]
-        cyc[-1] = [0, 14, 0] if nsm > 1 else cyc[-1]
-        scfg = {"coarsening": depth, "cycle": cyc, "restart": 3, "eo_levels": list(range(nsm)),
-                "setup": os.environ.get("SW_SYNTH_SETUP", "device"),
-                "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1}
+        # hierarchy.synthetic_solver_cfg: 8x8 site aggregates once, then 2x2 down to 16 x 16 sites, every
+        # level smoothed even-odd, a 2-step K-cycle on level 1 (profiles/r02_synthetic_lattices.txt,
+        # 1024^2: 408 probe-samples/s, 9 iterations; Schur steps on the lattice level: 10 -- 512^2: 1377
+        # probe-samples/s against 1331 with 14, 1024^2: 408 against 386, one more outer iteration)
+        scfg = swhier.synthetic_solver_cfg(Ls, int(os.environ.get("SW_SYNTH_NU0", "10")),
+                                           os.environ.get("SW_SYNTH_SETUP", "device"))
         if args.cfg:
             scfg = json.loads(args.cfg)
         mg = MG((Ls, -0.05, U1s, U2s))

@@ -68,10 +68,23 @@ def write_run_report(result, kind, params, elapsed_s, extra=None):
         rec.update(std_dev=float(result["std_dev"]), nr_ests=int(result["nr_ests"]),
                    function_iters=int(result["function_iters"]),
                    probe_samples_per_s=n / elapsed_s if elapsed_s > 0 else None)
+        if result.get("probe_loop_s"):
+            # the probe loop alone (setup, deflation vectors and the rough trace excluded): probes the
+            # GPU solved per second, and the ones the stopping rule ended up using
+            rec.update(probe_loop_s=float(result["probe_loop_s"]),
+                       probes_solved=int(result["probes_solved"]),
+                       probe_loop_solved_per_s=result["probes_solved"] / result["probe_loop_s"],
+                       probe_loop_used_per_s=n / result["probe_loop_s"])
     else:
         rec["levels"] = [{"nr_ests": int(r["nr_ests"]), "function_iters": int(r["function_iters"]),
                           "ests_avg": [float(np.real(r["ests_avg"])), float(np.imag(r["ests_avg"]))],
-                          "ests_dev": float(r["ests_dev"])} for r in result["results"]]
+                          "ests_dev": float(r["ests_dev"]),
+                          "probe_loop_s": float(r.get("probe_loop_s", 0.0)),
+                          "probes_solved": int(r.get("probes_solved", 0))} for r in result["results"]]
+        solved = sum(int(r.get("probes_solved", 0)) for r in result["results"])
+        loop_s = sum(float(r.get("probe_loop_s", 0.0)) for r in result["results"])
+        if loop_s > 0:
+            rec.update(probes_solved=solved, probe_loop_s=loop_s, probe_loop_solved_per_s=solved / loop_s)
     if extra:
         rec.update(extra)
     with open(path, "a") as f:

@@ -24,6 +24,8 @@ using swk::cplxf;
 using swk::PtrList;
 
 #define SW_MAXM 32  // engine restart cap (<= SW_MAX_KRYLOV)
+#define SW_NC_SLOTS 2048
+#define SW_TICKET_CHUNKS 128
 
 static std::string g_create_error;
 static int (*g_rccl_destroy)(void*) = nullptr;   // set when RCCL has been loaded (sw_comm_*)
@@ -187,6 +189,7 @@ struct sw_engine {
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
   bool lazy_sync = true;
+  bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
   bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
   int stencil_spw = 0;    // 0: automatic (4)
@@ -260,8 +263,18 @@ struct sw_engine {
   int64_t tcount[T_NCAT] = {0};
   double twork[T_NCAT] = {0};   // arithmetic issued per class while profiling (flops, MFMA classes)
   int64_t launches = 0;
-  int* d_notconv = nullptr;
+  // convergence counters: one slot per FGMRES scalar update of an outer solve (no per-iteration reset);
+  // the last slot is the sink of the inner solves, which nobody reads
+  int* d_notconv = nullptr;  // [SW_NC_SLOTS]
+  int nc_next = 0;
   int* h_notconv = nullptr;  // pinned
+  // tickets of the in-launch reductions (swk::reduce_and_tail), zero between launches
+  int* d_tick = nullptr;     // [SW_TICKET_CHUNKS * (SW_RED_MAXGROUPS + 1)]
+  bool fused_reduce = true;
+  // the batch is iterated until every probe's residual is below stop_factor * tol; iteration counts are
+  // reported at tol (multigrid.py:347-366).  1: the reference's stopping point; 0.1: per-probe estimates
+  // to 1e-10 relative even where the estimate cancels to a small number
+  double stop_factor = 1.0;
   void* comm = nullptr;      // RCCL communicator (sw_comm_init), one rank per engine
   double* d_stats = nullptr; // [4] all-reduce buffer
 };
@@ -650,20 +663,56 @@ static void row_blocking(int n, int nbp, bool reduce, int* P, int* rpb) {
   *P = (n + r - 1) / r;
 }
 
+// Reduction bookkeeping of the reducing BLAS-1 launches.  fused_reduce (default): the cross-workgroup
+// sum is completed inside the launch (last block done, two levels: swk::reduce_and_tail) and an FGMRES
+// scalar update (`tail`) may ride along; otherwise a second launch (k_reduce_partials) and, for a tail,
+// a third (k_fg_tail).
+static const swk::FgTail kNoTail = [] { swk::FgTail t{}; t.kind = SW_TAIL_NONE; return t; }();
+
+static bool fused_ok(sw_engine* h, int P, int nbp) {
+  return h->fused_reduce && h->d_tick && nbp / 64 <= SW_TICKET_CHUNKS &&
+         (P + SW_RED_GROUP - 1) / SW_RED_GROUP <= SW_RED_MAXGROUPS;
+}
+static swk::RedArgs red_args(sw_engine* h, bool fused, int P, int K, int nbp, cplx* out, const cplx* svec,
+                             cplx* coef) {
+  swk::RedArgs ra{};
+  if (fused) {
+    ra.tick1 = h->d_tick;
+    ra.tick2 = h->d_tick + SW_TICKET_CHUNKS * SW_RED_MAXGROUPS;
+    ra.gpart = h->partial + (size_t)P * K * nbp;
+    ra.out = out;
+    ra.svec = svec;
+    ra.coef = coef;
+  }
+  return ra;
+}
+static int launch_tail(sw_engine* h, const swk::FgTail& tail) {
+  LaunchScope ls(h, T_OTHER);
+  const int nbp = tail.s.nbp, tb = 256;
+  hipLaunchKernelGGL(swk::k_fg_tail, dim3((nbp + tb - 1) / tb), dim3(tb), 0, h->stream, tail);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
 // out[k][col] = sum_r conj(V_k[r]) W[r],  k < K
 template <class CV>
 static int multidot(sw_engine* h, const swk::PtrListT<CV>& V, int K, const CV* W, int n, int nbp,
-                    cplx* out, const cplx* svec = nullptr, cplx* coef = nullptr) {
+                    cplx* out, const cplx* svec = nullptr, cplx* coef = nullptr,
+                    const swk::FgTail* tail = nullptr) {
   if (K < 1 || K > SW_MAXM + 2) return sw_fail(h, "multidot: K=%d out of range", K);
   int P, rpb;
   row_blocking(n, nbp, true, &P, &rpb);
-  SWCHK(ensure_partial(h, (size_t)P * K * nbp * sizeof(cplx)));
+  const int ngroups = (P + SW_RED_GROUP - 1) / SW_RED_GROUP;
+  SWCHK(ensure_partial(h, (size_t)(P + ngroups) * K * nbp * sizeof(cplx)));
+  const bool fused = fused_ok(h, P, nbp);
+  const swk::RedArgs ra = red_args(h, fused, P, K, nbp, out, svec, coef);
+  const swk::FgTail tl = (fused && tail) ? *tail : kNoTail;
   dim3 grid(P, nbp / 64);
   {
     LaunchScope ls(h, T_DOTS);
 #define MD_CASE(KT)                                                                             \
   hipLaunchKernelGGL((swk::k_multidot<KT, CV>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, W, n, nbp, \
-                     rpb, h->partial)
+                     rpb, h->partial, ra, tl)
     if (K <= 2) MD_CASE(2);
     else if (K <= 4) MD_CASE(4);
     else if (K <= 8) MD_CASE(8);
@@ -673,12 +722,14 @@ static int multidot(sw_engine* h, const swk::PtrListT<CV>& V, int K, const CV* W
 #undef MD_CASE
     KLAUNCH_CHECK();
   }
+  if (fused) return 0;
   {
     LaunchScope ls(h, T_DOTS);
     hipLaunchKernelGGL(swk::k_reduce_partials, dim3(K, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
                        h->partial, P, K, nbp, out, svec, coef);
     KLAUNCH_CHECK();
   }
+  if (tail) SWCHK(launch_tail(h, *tail));
   return 0;
 }
 
@@ -686,11 +737,16 @@ static int multidot(sw_engine* h, const swk::PtrListT<CV>& V, int K, const CV* W
 template <class CV, class CW>
 static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx* coef, double sign,
                      const CW* Win, CW* Wout, int n, int nbp, cplx* nrm_out,
-                     cplxf* w32 = nullptr) {
+                     cplxf* w32 = nullptr, const swk::FgTail* tail = nullptr) {
   if (K < 1 || K > SW_MAXM + 2) return sw_fail(h, "multiaxpy: K=%d out of range", K);
+  if (tail && !nrm_out) return sw_fail(h, "internal: a reduction tail needs the fused norm");
   int P, rpb;
   row_blocking(n, nbp, nrm_out != nullptr, &P, &rpb);
-  if (nrm_out) SWCHK(ensure_partial(h, (size_t)P * nbp * sizeof(cplx)));
+  const int ngroups = (P + SW_RED_GROUP - 1) / SW_RED_GROUP;
+  if (nrm_out) SWCHK(ensure_partial(h, (size_t)(P + ngroups) * nbp * sizeof(cplx)));
+  const bool fused = nrm_out && fused_ok(h, P, nbp);
+  const swk::RedArgs ra = red_args(h, fused, P, 1, nbp, nrm_out, nullptr, nullptr);
+  const swk::FgTail tl = (fused && tail) ? *tail : kNoTail;
   dim3 grid(P, nbp / 64);
   {
     LaunchScope ls(h, T_AXPY);
@@ -698,10 +754,10 @@ static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx
   do {                                                                                           \
     if (nrm_out)                                                                                 \
       hipLaunchKernelGGL((swk::k_multiaxpy<KT, true, CV, CW>), grid, dim3(SW_BLOCK), 0, h->stream, V, K, \
-                         coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32);                   \
+                         coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32, ra, tl);           \
     else                                                                                         \
       hipLaunchKernelGGL((swk::k_multiaxpy<KT, false, CV, CW>), grid, dim3(SW_BLOCK), 0, h->stream, V, \
-                         K, coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32);                \
+                         K, coef, sign, Win, Wout, n, nbp, rpb, h->partial, w32, ra, tl);        \
   } while (0)
     if (K <= 2) MA_CASE(2);
     else if (K <= 4) MA_CASE(4);
@@ -712,12 +768,13 @@ static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx
 #undef MA_CASE
     KLAUNCH_CHECK();
   }
-  if (nrm_out) {
+  if (nrm_out && !fused) {
     LaunchScope ls(h, T_DOTS);
     hipLaunchKernelGGL(swk::k_reduce_partials, dim3(1, nbp / 64), dim3(SW_BLOCK), 0, h->stream,
                        h->partial, P, 1, nbp, nrm_out, (const cplx*)nullptr, (cplx*)nullptr);
     KLAUNCH_CHECK();
   }
+  if (tail && !fused) SWCHK(launch_tail(h, *tail));
   return 0;
 }
 
@@ -809,7 +866,6 @@ static int ensure_krylov(sw_engine* h, KrylovWS& w, int m, int n, int nbp, bool 
   SWCHK(dev_realloc(h, &w.h1, (size_t)(m + 2) * nbp));
   SWCHK(dev_realloc(h, &w.h2, (size_t)(m + 2) * nbp));
   SWCHK(dev_realloc(h, &w.nrm, (size_t)nbp));
-  w.sc.notconv = h->d_notconv;
   w.sc.m = m;
   w.sc.nbp = nbp;
   w.m = m;
@@ -823,7 +879,7 @@ static int ensure_krylov(sw_engine* h, KrylovWS& w, int m, int n, int nbp, bool 
 // ---------------------------------------------------------------------------------------------
 static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, double tol, int maxiter,
                   int m, bool outer, KrylovWS& ws, int nbp, int* iters_total,
-                  bool use_precond = true);
+                  bool use_precond = true, const cplx* aug = nullptr);
 
 // nu MR steps on (X, R) with R = B - A X maintained
 static int mr_smooth(sw_engine* h, Level& lv, cplx* X, cplx* R, int nu, int nbp) {
@@ -886,15 +942,19 @@ static int vec_add(sw_engine* h, const cplx* a, const cplx* b, cplx* dst, int n,
   return 0;
 }
 
-// E = gm_cycles x GMRES(gm_m) applied to A_l e = R from a zero guess (unpreconditioned)
+// E = gm_cycles x GMRES(gm_m) applied to A_l e = R from a zero guess (unpreconditioned).  With two cycles
+// and option lgmres_aug (default) the second cycle is LGMRES's: its search space is augmented by the
+// first cycle's correction, as SciPy's lgmres(maxiter=2, inner_m=30, outer_k=3) does at
+// multigrid.py:393-394,438-439 (the first outer iteration has nothing to augment with).
 static int gmres_smooth(sw_engine* h, Hier& H, int l, const cplx* R, cplx* E, int nbp) {
   Level& lv = H.lv[l];
   const int m = lv.gm_m;
-  SWCHK(ensure_krylov(h, lv.gws, m, lv.n, nbp, false));
+  const bool lg = h->lgmres_aug && lv.gm_cycles == 2 && m + 1 <= SW_MAXM;
+  SWCHK(ensure_krylov(h, lv.gws, lg ? m + 1 : m, lv.n, nbp, false));
   SWCHK(fgmres(h, H, l, R, E, 0.0, m, m, false, lv.gws, nbp, nullptr, false));
   for (int c = 1; c < lv.gm_cycles; ++c) {
     SWCHK(apply_op(h, lv, 1, E, R, lv.g1, nbp));                       // g1 = R - A E
-    SWCHK(fgmres(h, H, l, lv.g1, lv.g2, 0.0, m, m, false, lv.gws, nbp, nullptr, false));
+    SWCHK(fgmres(h, H, l, lv.g1, lv.g2, 0.0, m, m, false, lv.gws, nbp, nullptr, false, lg ? E : nullptr));
     SWCHK(vec_add(h, E, lv.g2, E, lv.n, nbp));
   }
   return 0;
@@ -1541,13 +1601,77 @@ static int vcycle_f32_boundary(sw_engine* h, Hier& H, int l, const cplx* Bin, cp
 }
 
 // ---------------------------------------------------------------------------------------------
+// convergence counters and the FGMRES scalar updates that ride on the reductions
+// ---------------------------------------------------------------------------------------------
+static int reset_slots(sw_engine* h) {
+  HIPCHK(hipMemsetAsync(h->d_notconv, 0, SW_NC_SLOTS * sizeof(int), h->stream));
+  h->nc_next = 0;
+  return 0;
+}
+// a zeroed counter for the next scalar update of an outer solve
+static int take_slot(sw_engine* h, int** slot) {
+  if (h->nc_next >= SW_NC_SLOTS - 1) SWCHK(reset_slots(h));
+  *slot = h->d_notconv + h->nc_next++;
+  return 0;
+}
+static inline int* sink_slot(sw_engine* h) { return h->d_notconv + SW_NC_SLOTS - 1; }
+// number of probes the update that owned `slot` left above tol_stop (drains the stream)
+static int read_slot(sw_engine* h, const int* slot, int* count) {
+  HIPCHK(hipMemcpyAsync(h->h_notconv, slot, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  SWCHK(stream_sync(h));
+  *count = *h->h_notconv;
+  return 0;
+}
+static swk::FgTail tail_begin(const KrylovWS& ws, int first_cycle) {
+  swk::FgTail t{};
+  t.kind = SW_TAIL_BEGIN;
+  t.s = ws.sc;
+  t.h1 = ws.nrm;
+  t.first_cycle = first_cycle;
+  return t;
+}
+static swk::FgTail tail_hess(const KrylovWS& ws, int j, bool two_pass, bool pyth, double tol, double tol_stop,
+                             int iter_base, int* slot) {
+  swk::FgTail t{};
+  t.kind = SW_TAIL_HESS;
+  t.s = ws.sc;
+  t.j = j;
+  t.h1 = ws.h1;
+  t.h2 = two_pass ? ws.h2 : nullptr;
+  t.nrm2 = pyth ? ws.h1 + (size_t)(j + 1) * ws.nbp : ws.nrm;
+  t.tol = tol;
+  t.tol_stop = tol_stop;
+  t.iter_base = iter_base;
+  t.pyth = pyth ? 1 : 0;
+  t.notconv = slot;
+  return t;
+}
+static swk::FgTail tail_verify(const KrylovWS& ws, double tol, double tol_stop, int* slot) {
+  swk::FgTail t{};
+  t.kind = SW_TAIL_VERIFY;
+  t.s = ws.sc;
+  t.h1 = ws.nrm;
+  t.tol = tol;
+  t.tol_stop = tol_stop;
+  t.notconv = slot;
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
 // batched right-preconditioned flexible GMRES(m) (MG.solve -> fgmres, multigrid.py:347-366);
 // one classical Gram-Schmidt pass per step (two with option cgs2), true-residual verification
-//  outer == true : restarted, converges every probe to tol (one host read-back per iteration)
-//  outer == false: exactly `maxiter` (= m) steps from a zero guess, no host synchronisation
+//  outer == true : restarted, converges every probe to stop_factor * tol (one host read-back per
+//                  iteration once the expected count is near)
+//  outer == false: exactly `maxiter` (= m, or m + 1 with `aug`) steps from a zero guess, no host
+//                  synchronisation
+//  aug (inner, unpreconditioned only): LGMRES's augmentation vector (multigrid.py:393-394, SciPy
+//                  lgmres with outer_k >= 1): after the m Arnoldi steps one more step whose direction
+//                  is `aug` instead of the next Krylov vector, so the cycle minimises the residual over
+//                  K_m(A, r) + span{aug}; ws must have room for m + 1 vectors
 // ---------------------------------------------------------------------------------------------
 static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, double tol, int maxiter,
-                  int m, bool outer, KrylovWS& ws, int nbp, int* iters_total, bool use_precond) {
+                  int m, bool outer, KrylovWS& ws, int nbp, int* iters_total, bool use_precond,
+                  const cplx* aug) {
   Level& lv = H.lv[level];
   const int hid_idx = (int)(&H - &h->hier[0]);
   const int check_from = (outer && h->lazy_sync) ? std::max(0, h->sync_hint[hid_idx][level] - 2) : 0;
@@ -1555,9 +1679,12 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
   const size_t vec = (size_t)n * nbp;
   const bool precond = use_precond && (level < H.nlevels - 1);
   const int tb = 256, tg = (nbp + tb - 1) / tb;
+  const double tol_stop = outer ? tol * h->stop_factor : tol;
+  if (aug && (outer || precond || ws.m < m + 1)) return sw_fail(h, "internal: augmented cycle misused");
   int done = 0;
   bool first = true;
   bool converged = false;
+  if (outer) SWCHK(reset_slots(h));
   SWCHK(zero_vec(h, X, n, nbp));
   const cplx* Rcur = B;
   // single-precision preconditioner: on the lattice level its directions are kept complex64 and its
@@ -1579,31 +1706,32 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
     {
       PtrList pl;
       pl.p[0] = Rcur;
-      SWCHK(multidot(h, pl, 1, Rcur, n, nbp, ws.nrm));
-      LaunchScope ls(h, T_OTHER);
-      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm,
-                         first ? 1 : 0, tol);
-      KLAUNCH_CHECK();
+      const swk::FgTail tbeg = tail_begin(ws, first ? 1 : 0);
+      SWCHK(multidot(h, pl, 1, Rcur, n, nbp, ws.nrm, nullptr, nullptr, &tbeg));
     }
-    // the basis is kept unnormalised (k_fg_hess): vtilde_0 is the residual where it lies,
+    // the basis is kept unnormalised (fg_hess_col): vtilde_0 is the residual where it lies,
     // vtilde_{j+1} the orthogonalised A M vtilde_j -- no normalisation passes over the vectors
     auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
     auto vt32 = [&](int k) -> const cplxf* { return k == 0 ? ws.v32 : ws.V32 + vec * (k - 1); };
     if (z32) SWCHK(cast_vec(h, Rcur, ws.v32, vec, T_AXPY));
     const bool two_pass = h->cgs2 || (!outer && h->inner_cgs2);
     int j = 0;
-    const int jmax = std::min(m, maxiter - done);
+    const int jmax = std::min(m, maxiter - done) + (aug ? 1 : 0);
     for (; j < jmax; ++j) {
       const cplx* vj = vt(j);
       cplx* zj = ws.Z + vec * j;
       cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
       cplxf* zj32 = z32 ? ws.Z32 + vec * j : nullptr;
+      const bool aug_step = aug && j == jmax - 1;
       // Last step of a cycle: vtilde_{j+1} is never used (the next cycle starts from the true
       // residual), only h_{j+1,j} is.  With one Gram-Schmidt pass that is
       // sqrt(|w|^2 - sum_k |h_{k,j}|^2): |w|^2 rides along in the same multidot pass over w and the
-      // orthogonalisation pass (j + 3 vector passes) is not run at all (k_fg_hess, pyth).
+      // orthogonalisation pass (j + 3 vector passes) is not run at all (fg_hess_col, pyth).
       const bool last = h->pyth_last && !two_pass && j == jmax - 1 && m <= 8;   // (short cycles only:
       // a single-pass basis of 30 vectors has lost too much orthogonality for the identity)
+      int* slot = sink_slot(h);
+      if (outer) SWCHK(take_slot(h, &slot));
+      const swk::FgTail th = tail_hess(ws, j, two_pass, last, tol, tol_stop, done, slot);
       if (k32) {
         // complex64 cycle: vtilde_j -> z_j -> w = A z_j -> orthogonalised vtilde_{j+1}, all stored
         // complex64 (the arithmetic of A z and of the inner products is fp64 on widened operands)
@@ -1613,22 +1741,24 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
         swk::PtrListT<cplxf> pv32;
         for (int k = 0; k <= j; ++k) pv32.p[k] = vt32(k);
         pv32.p[j + 1] = w32;
-        SWCHK(multidot(h, pv32, last ? j + 2 : j + 1, (const cplxf*)w32, n, nbp, ws.h1, ws.sc.svec, ws.c1));
+        SWCHK(multidot(h, pv32, last ? j + 2 : j + 1, (const cplxf*)w32, n, nbp, ws.h1, ws.sc.svec, ws.c1,
+                       last ? &th : nullptr));
         if (last) {
           // (nothing: h_{j+1,j} comes from the dots alone)
         } else if (two_pass) {
           SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, nullptr));
           SWCHK(multidot(h, pv32, j + 1, (const cplxf*)w32, n, nbp, ws.h2, ws.sc.svec, ws.c1));
-          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm));
+          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm, nullptr, &th));
         } else {
-          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm));
+          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n, nbp, ws.nrm, nullptr, &th));
         }
       } else {
       if (z32) {
         SWCHK(vcycle32(h, H, level, ws.v32, zj32, nbp));
         SWCHK((launch_stencil<cplxf, cplx>(h, lv, 0, zj32, nullptr, w, nbp, cplx{0.0, 0.0})));
       } else {
-        if (pf32) SWCHK(vcycle_f32_boundary(h, H, level, vj, zj, nbp));
+        if (aug_step) SWCHK(copy_vec(h, zj, aug, n, nbp));
+        else if (pf32) SWCHK(vcycle_f32_boundary(h, H, level, vj, zj, nbp));
         else if (precond) SWCHK(vcycle(h, H, level, vj, zj, nbp));
         else SWCHK(copy_vec(h, zj, vj, n, nbp));
         SWCHK(apply_op(h, lv, 0, zj, nullptr, w, nbp));
@@ -1637,35 +1767,26 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
       pv.p[j + 1] = w;
       // pass 1: raw dots d1 = Vt^H w, coefficients c = svec^2 d1 ; w -= Vt c
-      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1));
+      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n, nbp, ws.h1, ws.sc.svec, ws.c1, last ? &th : nullptr));
       if (last) {
         // (nothing: h_{j+1,j} comes from the dots alone)
       } else if (two_pass) {
         SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, nullptr));
         // pass 2 (re-orthogonalisation): d2 = Vt^H w ; w -= Vt (svec^2 d2) ; ||w||^2
         SWCHK(multidot(h, pv, j + 1, w, n, nbp, ws.h2, ws.sc.svec, ws.c1));
-        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr, &th));
       } else {
-        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr));
+        SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n, nbp, ws.nrm, z32 ? ws.v32 : nullptr, &th));
       }
       }   // fp64 basis
-      if (outer) HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
-      {
-        LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1,
-                           two_pass ? (const cplx*)ws.h2 : (const cplx*)nullptr,   // one pass: no second dots
-                           last ? (const cplx*)(ws.h1 + (size_t)(j + 1) * nbp) : (const cplx*)ws.nrm,
-                           tol, done, last ? 1 : 0);
-        KLAUNCH_CHECK();
-      }
       // read the flag back from the hinted iteration on, at the end of the budget, and in any
       // case every 8th iteration (a stale hint must never cost more than a few iterations)
-      if (outer && (done + j + 1 >= check_from || done + j + 1 >= maxiter ||
-                    ((done + j + 1) & 7) == 0)) {
-        HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost,
-                              h->stream));
-        SWCHK(stream_sync(h));
-        if (*h->h_notconv == 0) {
+      // (tol = 0: a fixed number of iterations, e.g. the relaxation sweeps of the setup -- nothing to poll)
+      if (outer && tol_stop > 0.0 && (done + j + 1 >= check_from || done + j + 1 >= maxiter ||
+                                      ((done + j + 1) & 7) == 0)) {
+        int left = 0;
+        SWCHK(read_slot(h, slot, &left));
+        if (left == 0) {
           converged = true;
           ++j;
           break;
@@ -1697,17 +1818,13 @@ static int fgmres(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, doub
       SWCHK(apply_op(h, lv, 1, X, B, ws.rres, nbp));
       PtrList pr;
       pr.p[0] = ws.rres;
-      SWCHK(multidot(h, pr, 1, ws.rres, n, nbp, ws.nrm));
-      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
-      {
-        LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_verify, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, tol);
-        KLAUNCH_CHECK();
-      }
-      HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost,
-                            h->stream));
-      SWCHK(stream_sync(h));
-      if (*h->h_notconv != 0) {
+      int* slot = nullptr;
+      SWCHK(take_slot(h, &slot));
+      const swk::FgTail tv = tail_verify(ws, tol, tol_stop, slot);
+      SWCHK(multidot(h, pr, 1, ws.rres, n, nbp, ws.nrm, nullptr, nullptr, &tv));
+      int left = 0;
+      SWCHK(read_slot(h, slot, &left));
+      if (left != 0) {
         converged = false;
         Rcur = ws.rres;
         continue;
@@ -1804,12 +1921,16 @@ int sw_create(sw_engine** out, int device_id) {
     return sw_fail(nullptr, "hipStreamCreate failed");
   }
   void* q = nullptr;
-  if (hipMalloc(&q, sizeof(int)) != hipSuccess ||
+  void* q2 = nullptr;
+  const size_t tick_bytes = (size_t)SW_TICKET_CHUNKS * (SW_RED_MAXGROUPS + 1) * sizeof(int);
+  if (hipMalloc(&q, SW_NC_SLOTS * sizeof(int)) != hipSuccess || hipMalloc(&q2, tick_bytes) != hipSuccess ||
+      hipMemset(q, 0, SW_NC_SLOTS * sizeof(int)) != hipSuccess || hipMemset(q2, 0, tick_bytes) != hipSuccess ||
       hipHostMalloc((void**)&h->h_notconv, sizeof(int)) != hipSuccess) {
     delete h;
-    return sw_fail(nullptr, "allocation of convergence flag failed");
+    return sw_fail(nullptr, "allocation of the convergence counters failed");
   }
   h->d_notconv = (int*)q;
+  h->d_tick = (int*)q2;
   *out = h;
   return 0;
 }
@@ -1826,6 +1947,7 @@ int sw_destroy(sw_engine* h) {
   }
   for (auto& e : h->evpool) (void)hipEventDestroy(e);
   if (h->d_notconv) (void)hipFree(h->d_notconv);
+  if (h->d_tick) (void)hipFree(h->d_tick);
   if (h->h_notconv) (void)hipHostFree(h->h_notconv);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2243,38 +2365,18 @@ int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* n
   return 0;
 }
 
-int sw_setup_invert_coarsest(sw_engine* h, int hid) {
-  SWCHK(check_hier(h, hid, 0, false));
-  HIPCHK(hipSetDevice(h->device));
-  Hier& H = h->hier[hid];
-  H.f32_valid = H.even_valid = false;
-  Level& lv = H.lv[H.nlevels - 1];
-  const EllOp& A = lv.A;
-  if (H.nlevels < 2 || !A.set || A.bsr_KS <= 0) return sw_fail(h, "coarsest level has no block-row operator");
-  const int n = lv.n;
-  if (n % 16) return sw_fail(h, "coarsest size %d is not a multiple of 16", n);
-  if (n > 8192) return sw_fail(h, "coarsest size %d too large for the in-engine dense inverse", n);
-  cplx* D = nullptr;
+// In-place inverse of the dense row-major n x n matrix D on the device: Gauss-Jordan with partial
+// pivoting (the device counterpart of np.linalg.inv at multigrid.py:342-344); hand-written kernels, no
+// library handle involved.  Four small launches per pivot step.
+static int gj_invert(sw_engine* h, cplx* D, int n) {
   cplx* colk = nullptr;
   cplx* pvinv = nullptr;
   int* pivs = nullptr;
-  SWCHK(dev_realloc(h, &D, (size_t)n * n));
   SWCHK(dev_realloc(h, &colk, (size_t)n));
   SWCHK(dev_realloc(h, &pvinv, (size_t)1));
   SWCHK(dev_realloc(h, &pivs, (size_t)n + 1));
   int* info = pivs + n;
-  HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
   HIPCHK(hipMemsetAsync(info, 0, sizeof(int), h->stream));
-  {
-    LaunchScope ls(h, T_OTHER);
-    const int items = (n / 16) * A.bsr_KS;
-    hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
-                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)A.bsr_vals, (const int*)A.bsr_kcol,
-                       n / 16, A.bsr_KS, n, D);
-    KLAUNCH_CHECK();
-  }
-  // Gauss-Jordan with partial pivoting, in place (the device counterpart of np.linalg.inv at
-  // multigrid.py:342-344); hand-written, no library handle involved
   {
     const dim3 g1((n + SW_BLOCK - 1) / SW_BLOCK);
     const dim3 gu((n + 63) / 64, (n + 16 * SW_WAVES_PER_BLOCK - 1) / (16 * SW_WAVES_PER_BLOCK));
@@ -2293,12 +2395,38 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   int hinfo = 0;
   HIPCHK(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   SWCHK(stream_sync(h));
-  if (hinfo != 0) {
+  SWCHK(dev_free(h, colk));
+  SWCHK(dev_free(h, pvinv));
+  SWCHK(dev_free(h, pivs));
+  if (hinfo != 0) return sw_fail(h, "Gauss-Jordan inverse: the matrix is singular");
+  return 0;
+}
+
+int sw_setup_invert_coarsest(sw_engine* h, int hid) {
+  SWCHK(check_hier(h, hid, 0, false));
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  H.f32_valid = H.even_valid = false;
+  Level& lv = H.lv[H.nlevels - 1];
+  const EllOp& A = lv.A;
+  if (H.nlevels < 2 || !A.set || A.bsr_KS <= 0) return sw_fail(h, "coarsest level has no block-row operator");
+  const int n = lv.n;
+  if (n % 16) return sw_fail(h, "coarsest size %d is not a multiple of 16", n);
+  if (n > 8192) return sw_fail(h, "coarsest size %d too large for the in-engine dense inverse", n);
+  cplx* D = nullptr;
+  SWCHK(dev_realloc(h, &D, (size_t)n * n));
+  HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
+  {
+    LaunchScope ls(h, T_OTHER);
+    const int items = (n / 16) * A.bsr_KS;
+    hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)A.bsr_vals, (const int*)A.bsr_kcol,
+                       n / 16, A.bsr_KS, n, D, (const int*)nullptr, (const int*)nullptr);
+    KLAUNCH_CHECK();
+  }
+  if (gj_invert(h, D, n) != 0) {
     (void)dev_free(h, D);
-    (void)dev_free(h, colk);
-    (void)dev_free(h, pvinv);
-    (void)dev_free(h, pivs);
-    return sw_fail(h, "coarsest operator is singular");
+    return 1;
   }
   SWCHK(free_op(h, H.cinv));
   EllOp& op = H.cinv;
@@ -2310,16 +2438,177 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
     LaunchScope ls(h, T_OTHER);
     const size_t items = (size_t)RT * KS;
     hipLaunchKernelGGL(swk::k_dense_to_bsr, dim3((unsigned)((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK)),
-                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)D, n, op.bsr_vals, op.bsr_kcol);
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)D, n, op.bsr_vals, op.bsr_kcol,
+                       (const int*)nullptr);
     KLAUNCH_CHECK();
   }
   op.bsr_KS = KS;
   op.set = true;
   SWCHK(stream_sync(h));
   SWCHK(dev_free(h, D));
-  SWCHK(dev_free(h, colk));
-  SWCHK(dev_free(h, pvinv));
-  SWCHK(dev_free(h, pivs));
+  return 0;
+}
+
+static int schur_apply(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* Bp, cplx* Y, int nbp);
+static int dot_into(sw_engine* h, const cplx* A, const cplx* Bv, int n, int nbp, cplx* out);
+
+// The dense inverse of a block level's even-odd Schur complement, formed ON THE DEVICE from the level's
+// Schur operator (eo_op[0], 9-point in 16 x 16 blocks over the even sites): S -> dense (ne*16)^2 ->
+// Gauss-Jordan -> block-row form over the even sites' tiles = even-odd operator 4, with which the cycle
+// solves the level exactly (vcycle_rich) instead of smoothing it.  Counterpart of np.linalg.inv at
+// multigrid.py:342-344 one level up.
+int sw_setup_direct_level(sw_engine* h, int hid, int level) {
+  SWCHK(check_hier(h, hid, level, false));
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  H.f32_valid = false;
+  Level& lv = H.lv[level];
+  const EllOp& S = lv.eo_op[0];
+  if (lv.stencil || !S.set || !S.bsr_tmap || S.bsr_RT <= 0 || !lv.eo_op[1].set || !lv.eo_op[2].set ||
+      !lv.eo_op[3].set)
+    return sw_fail(h, "level %d has no even-odd operators (sw_setup_eo_operators / sw_set_eo_operator)", level);
+  const int ne = S.bsr_RT, n = ne * 16, ns = lv.n / 16;
+  if (n > 8192) return sw_fail(h, "Schur complement of %d rows too large for the in-engine dense inverse", n);
+  std::vector<int> E(ne), erank(ns, -1);
+  HIPCHK(hipMemcpy(E.data(), S.bsr_tmap, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost));
+  for (int r = 0; r < ne; ++r) {
+    if (E[r] < 0 || E[r] >= ns || erank[E[r]] >= 0) return sw_fail(h, "level %d: bad tile map of the Schur operator", level);
+    erank[E[r]] = r;
+  }
+  std::vector<int> kc((size_t)ne * S.bsr_KS);
+  HIPCHK(hipMemcpy(kc.data(), S.bsr_kcol, kc.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int c : kc)
+    if (erank[c >> 4] < 0) return sw_fail(h, "level %d: the Schur operator reaches an odd site", level);
+  int *d_rank = nullptr, *d_E = nullptr;
+  SWCHK(upload(h, &d_rank, erank.data(), erank.size()));
+  SWCHK(upload(h, &d_E, E.data(), E.size()));
+  cplx* D = nullptr;
+  SWCHK(dev_realloc(h, &D, (size_t)n * n));
+  HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
+  {
+    LaunchScope ls(h, T_OTHER);
+    const int items = ne * S.bsr_KS;
+    hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)S.bsr_vals, (const int*)S.bsr_kcol, ne,
+                       S.bsr_KS, n, D, (const int*)d_rank, (const int*)nullptr);
+    KLAUNCH_CHECK();
+  }
+  if (gj_invert(h, D, n) != 0) {
+    (void)dev_free(h, D);
+    (void)dev_free(h, d_rank);
+    (void)dev_free(h, d_E);
+    return 1;
+  }
+  EllOp& op = lv.eo_op[4];
+  SWCHK(free_op(h, op));
+  op.nrows = op.ncols = lv.n;
+  op.bsr_RT = ne;
+  op.bsr_KS = n / 4;
+  SWCHK(upload(h, &op.bsr_tmap, E.data(), E.size()));
+  SWCHK(dev_realloc(h, &op.bsr_vals, (size_t)ne * op.bsr_KS * 64));
+  SWCHK(dev_realloc(h, &op.bsr_kcol, (size_t)ne * op.bsr_KS));
+  {
+    LaunchScope ls(h, T_OTHER);
+    const size_t items = (size_t)ne * op.bsr_KS;
+    hipLaunchKernelGGL(swk::k_dense_to_bsr, dim3((unsigned)((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK)),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)D, n, op.bsr_vals, op.bsr_kcol,
+                       (const int*)d_E);
+    KLAUNCH_CHECK();
+  }
+  op.set = true;
+  SWCHK(stream_sync(h));
+  SWCHK(dev_free(h, D));
+  SWCHK(dev_free(h, d_rank));
+  SWCHK(dev_free(h, d_E));
+  return 0;
+}
+
+// Arnoldi relation of a level's operator for the smoother polynomial (hierarchy.smoother_weights fits
+// the weights 1/theta_k to the harmonic Ritz values of H): `degree` steps from a pseudo-random start
+// vector, classical Gram-Schmidt twice, all on the device -- the host receives the (degree+1) x degree
+// Hessenberg matrix only (row-major complex128).  which = 0: the level operator A_l; which = 1: the
+// even-odd Schur complement S of the level (stencil level: half vectors through k_schur_step; block
+// levels: eo_op[0] on the even sites' rows).
+int sw_setup_arnoldi(sw_engine* h, int hid, int level, int which, int degree, uint64_t seed, double* Hout) {
+  SWCHK(check_hier(h, hid, level, false));
+  if (degree < 1 || degree > SW_MAXM || !Hout || (which != 0 && which != 1))
+    return sw_fail(h, "sw_setup_arnoldi: bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  Level& lv = H.lv[level];
+  if (lv.n <= 0 || (!lv.stencil && !lv.A.set)) return sw_fail(h, "level %d has no operator yet", level);
+  const bool schur = which == 1;
+  if (schur && !lv.stencil && !(lv.eo_op[0].set && lv.eo_op[0].bsr_tmap))
+    return sw_fail(h, "level %d has no even-odd Schur operator", level);
+  if (schur && lv.stencil && (lv.n % 2)) return sw_fail(h, "odd lattice level");
+  const int nbp = 64;
+  const int n = (schur && lv.stencil) ? lv.n / 2 : lv.n;     // rows of the vectors the operator acts on
+  const size_t vec = (size_t)n * nbp;
+  cplx* V = nullptr;      // degree + 1 basis vectors
+  cplx* d = nullptr;      // [2][degree + 1][nbp] dots of the two passes, + [nbp] norm
+  SWCHK(dev_realloc(h, &V, vec * (degree + 1)));
+  SWCHK(dev_realloc(h, &d, (size_t)(2 * (degree + 1) + 1) * nbp));
+  cplx* d1 = d;
+  cplx* d2 = d + (size_t)(degree + 1) * nbp;
+  cplx* nr = d + (size_t)2 * (degree + 1) * nbp;
+  auto normalise = [&](cplx* w) -> int {
+    LaunchScope ls(h, T_AXPY);
+    hipLaunchKernelGGL(swk::k_colscale, dim3(std::min(4096, (n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK), 1),
+                       dim3(SW_BLOCK), 0, h->stream, w, (const cplx*)nr, n, nbp);
+    KLAUNCH_CHECK();
+    return 0;
+  };
+  auto apply = [&](const cplx* x, cplx* y) -> int {
+    if (!schur) return apply_op(h, lv, 0, x, nullptr, y, nbp);
+    if (lv.stencil) return schur_apply(h, lv, 0, x, nullptr, y, nbp);
+    SWCHK(zero_vec(h, y, n, nbp));
+    return launch_bsr(h, lv.eo_op[0], 0, x, nullptr, y, nbp, T_MVM, cplx{0.0, 0.0});
+  };
+  // start vector: one pseudo-random column (the other 63 stay zero), on the rows the operator acts on
+  {
+    cplx* tmp = (schur && !lv.stencil) ? V + vec : V;
+    {
+      LaunchScope ls(h, T_OTHER);
+      hipLaunchKernelGGL(swk::k_fill_random, dim3((n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK), dim3(SW_BLOCK),
+                         0, h->stream, tmp, n, nbp, 1, (unsigned long long)(seed ? seed : 2024));
+      KLAUNCH_CHECK();
+    }
+    if (schur && !lv.stencil) {
+      SWCHK(zero_vec(h, V, n, nbp));
+      LaunchScope ls(h, T_OTHER);
+      const int items = lv.eo_op[0].bsr_RT * 16;
+      hipLaunchKernelGGL(swk::k_copy_tiles, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                         dim3(SW_BLOCK), 0, h->stream, (const cplx*)tmp, (const int*)lv.eo_op[0].bsr_tmap,
+                         lv.eo_op[0].bsr_RT, nbp, V);
+      KLAUNCH_CHECK();
+    }
+    SWCHK(dot_into(h, V, V, n, nbp, nr));
+    SWCHK(normalise(V));
+  }
+  std::vector<std::complex<double>> Hm((size_t)(degree + 1) * degree, std::complex<double>(0.0, 0.0));
+  std::vector<std::complex<double>> hd((size_t)(2 * (degree + 1) + 1) * nbp);
+  for (int j = 0; j < degree; ++j) {
+    cplx* w = V + vec * (j + 1);
+    SWCHK(apply(V + vec * j, w));
+    PtrList pv;
+    for (int k = 0; k <= j; ++k) pv.p[k] = V + vec * k;
+    SWCHK(multidot(h, pv, j + 1, (const cplx*)w, n, nbp, d1));
+    SWCHK(multiaxpy(h, pv, j + 1, d1, -1.0, (const cplx*)w, w, n, nbp, nullptr));
+    SWCHK(multidot(h, pv, j + 1, (const cplx*)w, n, nbp, d2));
+    SWCHK(multiaxpy(h, pv, j + 1, d2, -1.0, (const cplx*)w, w, n, nbp, nr));
+    SWCHK(stream_sync(h));
+    HIPCHK(hipMemcpy(hd.data(), d, hd.size() * sizeof(cplx), hipMemcpyDeviceToHost));
+    for (int k = 0; k <= j; ++k)
+      Hm[(size_t)k * degree + j] = hd[(size_t)k * nbp] + hd[(size_t)(degree + 1 + k) * nbp];
+    const double hn = std::sqrt(std::max(0.0, hd[(size_t)2 * (degree + 1) * nbp].real()));
+    Hm[(size_t)(j + 1) * degree + j] = hn;
+    if (!(hn > 0.0)) break;      // invariant subspace: the remaining columns stay zero
+    SWCHK(normalise(w));
+  }
+  SWCHK(stream_sync(h));
+  std::memcpy(Hout, Hm.data(), Hm.size() * sizeof(std::complex<double>));
+  SWCHK(dev_free(h, V));
+  SWCHK(dev_free(h, d));
   return 0;
 }
 
@@ -2776,6 +3065,19 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->f32_dense_stages = (int)value;
     return 0;
   }
+  if (std::strcmp(name, "stop_factor") == 0) {
+    if (!(value > 0.0 && value <= 1.0)) return sw_fail(h, "stop_factor must be in (0, 1]");
+    h->stop_factor = value;
+    return 0;
+  }
+  if (std::strcmp(name, "fused_reduce") == 0) {
+    h->fused_reduce = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "lgmres_aug") == 0) {
+    h->lgmres_aug = value != 0.0;
+    return 0;
+  }
   if (std::strcmp(name, "verify") == 0) {
     h->verify = value != 0.0;
     return 0;
@@ -3083,7 +3385,9 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
   const int n2 = lv.n / 2;
   const size_t vec = (size_t)n2 * nbp;
   const int tb = 256, tg = (nbp + tb - 1) / tb;
+  const double tol_stop = tol * h->stop_factor;
   SWCHK(ensure_level_ws(h, lv, nbp));
+  SWCHK(reset_slots(h));
   swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
   const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
   const dim3 grid(bpc * (nbp / 64));
@@ -3104,12 +3408,8 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
     // ||b|| of the FULL system fixes normb (the reference's stopping criterion); b'_e = b_e + H_eo b_o / D
     PtrList pl;
     pl.p[0] = B;
-    SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm));
-    {
-      LaunchScope ls(h, T_OTHER);
-      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 1, tol);
-      KLAUNCH_CHECK();
-    }
+    const swk::FgTail tbeg = tail_begin(ws, 1);
+    SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm, nullptr, nullptr, &tbeg));
     LaunchScope ls(h, T_SCHUR);
     hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, B, B, bp, a, 1.0, di, bpc);
     KLAUNCH_CHECK();
@@ -3126,10 +3426,8 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
     {
       PtrList pl;
       pl.p[0] = Rcur;
-      SWCHK(multidot(h, pl, 1, Rcur, n2, nbp, ws.nrm));
-      LaunchScope ls(h, T_OTHER);
-      hipLaunchKernelGGL(swk::k_fg_begin, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, 0, tol);
-      KLAUNCH_CHECK();
+      const swk::FgTail tbeg = tail_begin(ws, 0);
+      SWCHK(multidot(h, pl, 1, Rcur, n2, nbp, ws.nrm, nullptr, nullptr, &tbeg));
     }
     auto vt = [&](int k) -> const cplx* { return k == 0 ? Rcur : ws.V + vec * (k - 1); };
     auto vt32 = [&](int k) -> const cplxf* { return k == 0 ? ws.v32 : ws.V32 + vec * (k - 1); };
@@ -3140,6 +3438,9 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
       cplx* zj = ws.Z + vec * j;
       cplx* w = ws.V + vec * j;          // becomes vtilde_{j+1}
       const bool last = h->pyth_last && j == jmax - 1 && m <= 8;
+      int* slot = nullptr;
+      SWCHK(take_slot(h, &slot));
+      const swk::FgTail th = tail_hess(ws, j, false, last, tol, tol_stop, done, slot);
       if (k32) {
         cplxf* zj32 = ws.Z32 + vec * j;
         cplxf* w32 = ws.V32 + vec * j;
@@ -3148,30 +3449,23 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
         swk::PtrListT<cplxf> pv32;
         for (int k = 0; k <= j; ++k) pv32.p[k] = vt32(k);
         pv32.p[j + 1] = w32;
-        SWCHK(multidot(h, pv32, last ? j + 2 : j + 1, (const cplxf*)w32, n2, nbp, ws.h1, ws.sc.svec, ws.c1));
-        if (!last) SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n2, nbp, ws.nrm));
+        SWCHK(multidot(h, pv32, last ? j + 2 : j + 1, (const cplxf*)w32, n2, nbp, ws.h1, ws.sc.svec, ws.c1,
+                       last ? &th : nullptr));
+        if (!last)
+          SWCHK(multiaxpy(h, pv32, j + 1, ws.c1, -1.0, (const cplxf*)w32, w32, n2, nbp, ws.nrm, nullptr, &th));
       } else {
       SWCHK(vcycle_even(h, H, vt(j), zj, nbp));
       SWCHK(schur_apply(h, lv, 0, zj, nullptr, w, nbp));
       PtrList pv;
       for (int k = 0; k <= j; ++k) pv.p[k] = vt(k);
       pv.p[j + 1] = w;
-      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n2, nbp, ws.h1, ws.sc.svec, ws.c1));
-      if (!last) SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n2, nbp, ws.nrm));
-      }
-      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
-      {
-        LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_hess, dim3(tg), dim3(tb), 0, h->stream, ws.sc, j, ws.h1,
-                           (const cplx*)nullptr,
-                           last ? (const cplx*)(ws.h1 + (size_t)(j + 1) * nbp) : (const cplx*)ws.nrm,
-                           tol, done, last ? 1 : 0);
-        KLAUNCH_CHECK();
+      SWCHK(multidot(h, pv, last ? j + 2 : j + 1, w, n2, nbp, ws.h1, ws.sc.svec, ws.c1, last ? &th : nullptr));
+      if (!last) SWCHK(multiaxpy(h, pv, j + 1, ws.c1, -1.0, w, w, n2, nbp, ws.nrm, nullptr, &th));
       }
       if (done + j + 1 >= check_from || done + j + 1 >= maxiter || ((done + j + 1) & 7) == 0) {
-        HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        SWCHK(stream_sync(h));
-        if (*h->h_notconv == 0) {
+        int left = 0;
+        SWCHK(read_slot(h, slot, &left));
+        if (left == 0) {
           converged = true;
           ++j;
           break;
@@ -3199,16 +3493,13 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
       SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
       PtrList pr;
       pr.p[0] = ws.rres;
-      SWCHK(multidot(h, pr, 1, ws.rres, n2, nbp, ws.nrm));
-      HIPCHK(hipMemsetAsync(h->d_notconv, 0, sizeof(int), h->stream));
-      {
-        LaunchScope ls(h, T_OTHER);
-        hipLaunchKernelGGL(swk::k_fg_verify, dim3(tg), dim3(tb), 0, h->stream, ws.sc, ws.nrm, tol);
-        KLAUNCH_CHECK();
-      }
-      HIPCHK(hipMemcpyAsync(h->h_notconv, h->d_notconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      SWCHK(stream_sync(h));
-      if (*h->h_notconv != 0) {
+      int* slot = nullptr;
+      SWCHK(take_slot(h, &slot));
+      const swk::FgTail tv = tail_verify(ws, tol, tol_stop, slot);
+      SWCHK(multidot(h, pr, 1, ws.rres, n2, nbp, ws.nrm, nullptr, nullptr, &tv));
+      int left = 0;
+      SWCHK(read_slot(h, slot, &left));
+      if (left != 0) {
         converged = false;
         Rcur = ws.rres;
         continue;
@@ -3645,7 +3936,16 @@ Rccl g_rccl;
 bool load_rccl() {
   if (g_rccl.tried) return g_rccl.ok;
   g_rccl.tried = true;
-  g_rccl.lib = dlopen("librccl.so", RTLD_NOW);
+  // A process that runs torch.distributed with backend nccl already has RCCL mapped (PyTorch's bundled
+  // copy); a second copy of a ROCm library in one process is what broke rocBLAS handle creation earlier
+  // (two HIP runtimes' worth of static state), so: the mapped one first (RTLD_NOLOAD), by the names it
+  // goes by, and only then a fresh load.
+  for (const char* nm : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) g_rccl.lib = dlopen(nullptr, RTLD_NOW);
+  if (!g_rccl.lib) g_rccl.lib = dlopen("librccl.so", RTLD_NOW);
   if (!g_rccl.lib) g_rccl.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW);
   if (!g_rccl.lib) return false;
   g_rccl.get_uid = (int (*)(RcclUid*))dlsym(g_rccl.lib, "ncclGetUniqueId");

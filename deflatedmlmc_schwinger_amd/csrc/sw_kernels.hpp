@@ -1297,6 +1297,316 @@ __global__ __launch_bounds__(SW_MT_BLOCK) void k_mt_generate(const uint32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-probe scalars of the batched flexible GMRES (one thread per probe).
+// Storage: H [(m+1)][m][nbp], cs [m][nbp] (.x), sn [m][nbp], g [(m+1)][nbp].
+// The three updates below (start of a cycle, Hessenberg column, true-residual check) each consume the
+// result of ONE reduction; they run either as the small kernel k_fg_tail or -- option fused_reduce -- in
+// the tail of the reducing launch itself (FgTail, reduce_and_tail): the workgroup that completes a
+// probe chunk's reduction applies the update to that chunk's 64 columns.
+// Two tolerances: `tol` is the reference's (a probe's reported iteration count is the first iteration
+// at which its residual passes it, multigrid.py:347-366), `tol_stop` <= tol is what the batch is
+// iterated to (engine option stop_factor; tol_stop = tol reproduces the reference's stopping point).
+// ------------------------------------------------------------------------------------------
+struct FgScalars {
+  cplx* H;
+  cplx* cs;
+  cplx* sn;
+  cplx* g;
+  cplx* y;        // [m][nbp]
+  cplx* normb;    // [nbp] .x
+  cplx* relres;   // [nbp] .x
+  cplx* svec;     // [(m+1)][nbp] .x: scale of basis vector k, v_k = svec_k * vtilde_k (0: frozen)
+  cplx* ys;       // [m][nbp] y_k * svec_k: coefficients of the update x += sum_k ys_k ztilde_k
+  int* iters;     // [nbp] iteration at which the probe first met tol (-1: not yet)
+  int m;
+  int nbp;
+};
+
+#define SW_TAIL_NONE 0
+#define SW_TAIL_BEGIN 1
+#define SW_TAIL_HESS 2
+#define SW_TAIL_VERIFY 3
+struct FgTail {
+  int kind;
+  FgScalars s;
+  int j;               // HESS: column of the Hessenberg matrix
+  const cplx* h1;      // HESS: raw dots of pass 1;  BEGIN / VERIFY: d[col].x = the squared norm
+  const cplx* h2;      // HESS: raw dots of the second Gram-Schmidt pass, or NULL
+  const cplx* nrm2;    // HESS: |vtilde_{j+1}|^2 (pyth: |A ztilde_j|^2)
+  double tol, tol_stop;
+  int iter_base, pyth, first_cycle;
+  int* notconv;        // HESS / VERIFY: counter of the probes still above tol_stop (zero on entry)
+};
+
+// start of a cycle: beta = sqrt(d[col].x);  first cycle also fixes normb
+__device__ __forceinline__ void fg_begin_col(const FgScalars& s, const cplx* __restrict__ d,
+                                             int first_cycle, int col) {
+  const double beta = sqrt(fmax(d[col].x, 0.0));
+  if (first_cycle) {
+    s.normb[col] = cmake(beta, 0.0);
+    s.iters[col] = (beta > 0.0) ? -1 : 0;
+    s.relres[col] = cmake(beta > 0.0 ? 1.0 : 0.0, 0.0);
+  }
+  s.g[col] = cmake(beta, 0.0);
+  s.svec[col] = cmake(beta > 0.0 ? 1.0 / beta : 0.0, 0.0);   // vtilde_0 = r itself
+}
+
+// Column j of the Hessenberg matrix.  The Krylov basis is kept UNNORMALISED in memory: the stored
+// vtilde_k and the true orthonormal v_k differ by a per-probe scale, v_k = svec_k vtilde_k (vtilde_0
+// is the residual itself, vtilde_{k+1} the orthogonalised A M vtilde_k as multiaxpy leaves it), so no
+// pass over the vectors is spent on normalisation; the multigrid cycle and A are linear, so
+// ztilde_k = M vtilde_k and z_k = svec_k ztilde_k.  With the raw dots d_k = vtilde_k^H (A ztilde_j)
+// (d1 + d2: two Gram-Schmidt passes) and nrm2 = |vtilde_{j+1}|^2:
+//   h_{k,j} = svec_k svec_j d_k,   h_{j+1,j} = svec_j sqrt(nrm2),   svec_{j+1} = 1/sqrt(nrm2)
+// (the orthogonalisation coefficients svec_k^2 d_k come from the reduction).
+__device__ __forceinline__ void fg_hess_col(const FgScalars& s, int j, const cplx* __restrict__ h1,
+                                            const cplx* __restrict__ h2, const cplx* __restrict__ nrm2,
+                                            double tol, double tol_stop, int iter_base, int pyth,
+                                            int* notconv, int col) {
+  const int m = s.m, nbp = s.nbp;
+  const double sj = s.svec[(size_t)j * nbp + col].x;
+  // apply the previous rotations
+  const double s0 = s.svec[col].x * sj;
+  cplx hk = h2 ? cadd(h1[col], h2[col]) : h1[col];     // h2 == NULL: one Gram-Schmidt pass
+  hk = cmake(s0 * hk.x, s0 * hk.y);
+  double hcol2 = hk.x * hk.x + hk.y * hk.y;      // |h_{0..j,j}|^2 before the rotations
+  for (int k = 0; k < j; ++k) {
+    const double sk1 = s.svec[(size_t)(k + 1) * nbp + col].x * sj;
+    cplx hk1 = h1[(size_t)(k + 1) * nbp + col];
+    if (h2) hk1 = cadd(hk1, h2[(size_t)(k + 1) * nbp + col]);
+    hk1 = cmake(sk1 * hk1.x, sk1 * hk1.y);
+    hcol2 = fma(hk1.x, hk1.x, fma(hk1.y, hk1.y, hcol2));
+    const double c = s.cs[(size_t)k * nbp + col].x;
+    const cplx sn = s.sn[(size_t)k * nbp + col];
+    // [ c  sn ; -conj(sn)  c ]
+    cplx t = cmake(c * hk.x, c * hk.y);
+    cfma(t, sn, hk1);
+    cplx u = cmake(c * hk1.x, c * hk1.y);
+    cfma(u, cmake(-sn.x, sn.y), hk);
+    s.H[((size_t)k * m + j) * nbp + col] = t;
+    hk = u;
+  }
+  // h_{j+1,j} = hn.  pyth == 0: nrm2 = |vtilde_{j+1}|^2 of the orthogonalised vector.  pyth == 1
+  // (last step of a restart cycle, whose vtilde_{j+1} is never used and therefore never formed):
+  // nrm2 = |A ztilde_j|^2 BEFORE the orthogonalisation, and with one classical Gram-Schmidt pass
+  // |h_{j+1,j}|^2 = svec_j^2 |A ztilde_j|^2 - sum_k |h_{k,j}|^2; a remainder below 1e-12 of the
+  // total is round-off of that subtraction and counts as breakdown (the solve is then settled by
+  // the true-residual verification)
+  double wn, hn;
+  if (pyth) {
+    const double tot = sj * sj * fmax(nrm2[col].x, 0.0);
+    double h2v = tot - hcol2;
+    if (!(h2v > 1.0e-12 * tot)) h2v = 0.0;
+    hn = sqrt(h2v);
+    wn = (sj > 0.0) ? hn / sj : 0.0;
+  } else {
+    wn = sqrt(fmax(nrm2[col].x, 0.0));
+    hn = sj * wn;
+  }
+  // new rotation annihilating h_{j+1,j} = hn
+  const double habs = sqrt(hk.x * hk.x + hk.y * hk.y);
+  const double dnm = sqrt(habs * habs + hn * hn);
+  double c;
+  cplx sn;
+  if (dnm == 0.0) {
+    c = 1.0;
+    sn = cmake(0.0, 0.0);
+  } else if (habs == 0.0) {
+    c = 0.0;
+    sn = cmake(1.0, 0.0);
+  } else {
+    c = habs / dnm;
+    const double f = hn / (habs * dnm);
+    sn = cmake(hk.x * f, hk.y * f);  // (a/|a|) * conj(b)/d, b = hn real
+  }
+  s.cs[(size_t)j * nbp + col] = cmake(c, 0.0);
+  s.sn[(size_t)j * nbp + col] = sn;
+  cplx hjj = cmake(c * hk.x, c * hk.y);
+  cfma(hjj, sn, cmake(hn, 0.0));
+  s.H[((size_t)j * m + j) * nbp + col] = hjj;
+  const cplx gj = s.g[(size_t)j * nbp + col];
+  const cplx gn = cmul(cmake(-sn.x, sn.y), gj);
+  s.g[(size_t)(j + 1) * nbp + col] = gn;
+  s.g[(size_t)j * nbp + col] = cmake(c * gj.x, c * gj.y);
+  const double nb_ = s.normb[col].x;
+  const double rr = (nb_ > 0.0) ? sqrt(gn.x * gn.x + gn.y * gn.y) / nb_ : 0.0;
+  const bool dead = (hn == 0.0 && hcol2 == 0.0);     // frozen earlier: w = 0, rr is meaningless
+  if (!dead) s.relres[col] = cmake(rr, 0.0);
+  if (s.iters[col] < 0 && rr < tol) s.iters[col] = iter_base + j + 1;
+  if (!dead && !(rr < tol_stop)) atomicAdd(notconv, 1);
+  // Next basis vector v_{j+1} = w / h_{j+1,j}.  Probes that have met tol_stop keep iterating in
+  // lockstep with the batch (free extra accuracy) until they are two orders below it; then, or at
+  // (happy) breakdown h_{j+1,j} <= 1e-14 |A z_j| where the remainder is round-off that 1/h would
+  // blow up to a unit vector, the probe is FROZEN: scale 0 makes v_{j+1}, hence z, w and every
+  // later Hessenberg column of this probe exactly zero, and k_fg_solve gives y = 0 for them.
+  const bool frozen = (s.iters[col] >= 0 && rr < 1.0e-2 * tol_stop) ||
+                      (hn * hn <= 1.0e-28 * (hcol2 + hn * hn));
+  s.svec[(size_t)(j + 1) * nbp + col] = cmake((hn > 0.0 && !frozen) ? 1.0 / wn : 0.0, 0.0);
+}
+
+// true-residual check after a solve: d[col].x = ||b - A x||^2; probes above tol lose their recorded
+// iteration (it is set again when they converge in a later cycle), probes above tol_stop are counted
+__device__ __forceinline__ void fg_verify_col(const FgScalars& s, const cplx* __restrict__ d, double tol,
+                                              double tol_stop, int* notconv, int col) {
+  const double nb_ = s.normb[col].x;
+  const double rr = (nb_ > 0.0) ? sqrt(fmax(d[col].x, 0.0)) / nb_ : 0.0;
+  s.relres[col] = cmake(rr, 0.0);
+  if (!(rr < tol)) s.iters[col] = -1;
+  if (!(rr < tol_stop)) atomicAdd(notconv, 1);
+}
+
+__device__ __forceinline__ void fg_tail_col(const FgTail& t, int col) {
+  if (t.kind == SW_TAIL_BEGIN) fg_begin_col(t.s, t.h1, t.first_cycle, col);
+  else if (t.kind == SW_TAIL_HESS)
+    fg_hess_col(t.s, t.j, t.h1, t.h2, t.nrm2, t.tol, t.tol_stop, t.iter_base, t.pyth, t.notconv, col);
+  else if (t.kind == SW_TAIL_VERIFY) fg_verify_col(t.s, t.h1, t.tol, t.tol_stop, t.notconv, col);
+}
+
+// the same updates as a kernel of their own (fused_reduce off, or no reduction precedes them)
+__global__ void k_fg_tail(FgTail t) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= t.s.nbp) return;
+  fg_tail_col(t, col);
+}
+
+// y = H(0:k,0:k)^-1 g(0:k) per probe
+__global__ void k_fg_solve(FgScalars s, int k) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= s.nbp) return;
+  const int m = s.m, nbp = s.nbp;
+  for (int i = k - 1; i >= 0; --i) {
+    cplx t = s.g[(size_t)i * nbp + col];
+    for (int l = i + 1; l < k; ++l) {
+      const cplx hl = s.H[((size_t)i * m + l) * nbp + col];
+      const cplx yl = s.y[(size_t)l * nbp + col];
+      cfma(t, cmake(-hl.x, -hl.y), yl);
+    }
+    const cplx hii = s.H[((size_t)i * m + i) * nbp + col];
+    const double dd = hii.x * hii.x + hii.y * hii.y;
+    cplx yi = cmake(0.0, 0.0);
+    if (dd > 0.0) yi = cmake((t.x * hii.x + t.y * hii.y) / dd, (t.y * hii.x - t.x * hii.y) / dd);
+    s.y[(size_t)i * nbp + col] = yi;
+    const double si = s.svec[(size_t)i * nbp + col].x;
+    s.ys[(size_t)i * nbp + col] = cmake(si * yi.x, si * yi.y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Completion of a cross-workgroup reduction INSIDE the launch that produced the partial sums
+// ("last block done", two levels).  grid = (P row blocks, probe chunks); block p of a chunk has
+// written partial[(p K + k) nbp + col] for its rows.  Blocks are grouped by SW_RED_GROUP consecutive p:
+// the block that completes a group (ticket counter) adds the group's partials in the order of p into
+// gpart[(g K + k) nbp + col]; the block that completes the last group adds the group sums in the order
+// of g and writes out / coef, then applies `tail` to the chunk's 64 columns.  Which block does the
+// adding depends on timing, the order of every sum does not: results are bit-reproducible, no
+// floating-point atomics.  Tickets are zero on entry and left zero.  Two levels keep the data one CU has
+// to pull small (a single finishing block would read P K KiB per chunk through one L1).
+// Visibility: partials are released device-wide (__threadfence) before the ticket is taken and
+// acquired (__threadfence) by the block that finds itself last.
+// ------------------------------------------------------------------------------------------
+#define SW_RED_GROUP 32
+
+struct RedArgs {
+  int* tick1;           // [chunks][SW_RED_MAXGROUPS]
+  int* tick2;           // [chunks]
+  cplx* gpart;          // [groups][K][nbp]
+  cplx* out;            // [K][nbp]
+  const cplx* svec;     // optional, with coef: coef[k] = svec[k].x^2 out[k]
+  cplx* coef;
+};
+#define SW_RED_MAXGROUPS 64
+
+// sums `cnt` entries src[i * stride] (i < cnt) for KB values of k at a time: the four waves take
+// i = wave, wave + 4, ... each, combine through LDS in wave order
+// (red: KB * 4 * 64 values of LDS)
+template <bool FINAL, int KB>
+__device__ __forceinline__ void red_sum_block(const cplx* __restrict__ src, size_t istride, int cnt, int K,
+                                              int nbp, size_t col, cplx* __restrict__ dst,
+                                              const cplx* __restrict__ svec, cplx* __restrict__ coef,
+                                              cplx* red) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int kb = 0; kb < K; kb += KB) {
+    const int kn = min(KB, K - kb);
+    for (int kk = 0; kk < kn; ++kk) {
+      const cplx* sp = src + (size_t)(kb + kk) * nbp + col;
+      cplx a0 = cmake(0.0, 0.0), a1 = a0;
+      int i = wave;
+      for (; i + 4 < cnt; i += 8) {
+        const cplx u = sp[(size_t)i * istride];
+        const cplx v = sp[(size_t)(i + 4) * istride];
+        a0 = cadd(a0, u);
+        a1 = cadd(a1, v);
+      }
+      if (i < cnt) a0 = cadd(a0, sp[(size_t)i * istride]);
+      red[(kk * 4 + wave) * 64 + lane] = cadd(a0, a1);
+    }
+    __syncthreads();
+    for (int kk = wave; kk < kn; kk += 4) {
+      const cplx* rk = red + (size_t)kk * 256 + lane;
+      const cplx t = cadd(cadd(rk[0], rk[64]), cadd(rk[128], rk[192]));
+      const size_t o = (size_t)(kb + kk) * nbp + col;
+      dst[o] = t;
+      if (FINAL && coef) {
+        const double q = svec[o].x;
+        coef[o] = cmake(q * q * t.x, q * q * t.y);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// called by ALL threads of every block after the block's partials are stored (by any of its threads);
+// red: KB * 256 values of LDS the caller no longer needs
+template <int KB>
+__device__ __forceinline__ void reduce_and_tail(const cplx* __restrict__ partial, int K, int nbp,
+                                                const RedArgs& ra, const FgTail& tail, cplx* red) {
+  __shared__ int s_flag;
+  const int P = gridDim.x, p = blockIdx.x, chunk = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const size_t col = (size_t)chunk * 64 + lane;
+  const int ngroups = (P + SW_RED_GROUP - 1) / SW_RED_GROUP;
+  const int g = p / SW_RED_GROUP;
+  const int g0 = g * SW_RED_GROUP;
+  const int gcnt = min(SW_RED_GROUP, P - g0);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* t1 = ra.tick1 + chunk * SW_RED_MAXGROUPS + g;
+    const int last = (atomicAdd(t1, 1) == gcnt - 1);
+    if (last) atomicExch(t1, 0);
+    s_flag = last;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  __threadfence();
+  const size_t pstride = (size_t)K * nbp;
+  if (ngroups == 1) {
+    red_sum_block<true, KB>(partial, pstride, gcnt, K, nbp, col, ra.out, ra.svec, ra.coef, red);
+  } else {
+    red_sum_block<false, KB>(partial + (size_t)g0 * pstride, pstride, gcnt, K, nbp, col,
+                         ra.gpart + (size_t)g * pstride, nullptr, nullptr, red);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int* t2 = ra.tick2 + chunk;
+      const int last = (atomicAdd(t2, 1) == ngroups - 1);
+      if (last) atomicExch(t2, 0);
+      s_flag = last;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    __threadfence();
+    red_sum_block<true, KB>(ra.gpart, pstride, ngroups, K, nbp, col, ra.out, ra.svec, ra.coef, red);
+  }
+  if (tail.kind != SW_TAIL_NONE) {
+    // (the sums were stored by this block's own threads: a block-level barrier orders them)
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 64) fg_tail_col(tail, (int)col);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Batched BLAS-1.  All of them: lane == probe, grid.y == 64-probe chunk.
 // ------------------------------------------------------------------------------------------
 #define SW_MAXK 34   // restart cap 32, + w itself + 1
@@ -1310,10 +1620,11 @@ typedef PtrListT<cplx> PtrList;
 // partial[(blockIdx.x*K + k)*nbp + col] = sum over this block's rows of conj(V_k[r]) * W[r]
 // CV: storage type of V and W (complex64 for the Krylov basis of the single-precision cycle mode);
 // products and sums are fp64 either way
+// fused (RedArgs::tick1 != NULL): the reduction is completed, and `tail` applied, inside this launch
 template <int KT, class CV = cplx>
 __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrListT<CV> V, int K, const CV* __restrict__ W,
                                                        int n, int nbp, int rows_per_block,
-                                                       cplx* __restrict__ partial) {
+                                                       cplx* __restrict__ partial, RedArgs ra, FgTail tail) {
   __shared__ cplx red[3][8][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t col = (size_t)blockIdx.y * 64 + lane;
@@ -1355,6 +1666,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrListT<CV> V, int K, co
     }
     __syncthreads();
   }
+  if (ra.tick1) reduce_and_tail<6>(partial, K, nbp, ra, tail, &red[0][0][0]);
 }
 
 // out[k*nbp + col] = sum_p partial[(p*K + k)*nbp + col]
@@ -1414,8 +1726,9 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrListT<CV> V, int K,
                                                         CW* __restrict__ Wout, int n, int nbp,
                                                         int rows_per_block,
                                                         cplx* __restrict__ partial,
-                                                        cplxf* __restrict__ W32) {
+                                                        cplxf* __restrict__ W32, RedArgs ra, FgTail tail) {
   __shared__ double redn[3][64];
+  __shared__ cplx redt[NORM ? 256 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t col = (size_t)blockIdx.y * 64 + lane;
   const int r0 = blockIdx.x * rows_per_block;
@@ -1451,6 +1764,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multiaxpy(PtrListT<CV> V, int K,
       nrm += redn[2][lane];
       partial[(size_t)blockIdx.x * nbp + col] = cmake(nrm, 0.0);
     }
+    if (ra.tick1) reduce_and_tail<1>(partial, 1, nbp, ra, tail, redt);
   }
 }
 
@@ -1694,30 +2008,63 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_from_probe(const cplx* __restr
   if (lane == 0) kcol[item] = S * 16 + 4 * g;
 }
 
-// block-row operator -> dense row-major [n][n] (D zeroed by the caller); one wave per (rt, ks)
+// block-row operator -> dense row-major [n][n] (D zeroed by the caller); one wave per (rt, ks).
+// colrank (optional): the operator's columns belong to a SUBSET of the level's 16-row site tiles, and
+// colrank[site] is that site's tile index in the dense matrix (the even sites of a Schur complement)
 __global__ __launch_bounds__(SW_BLOCK) void k_bsr_to_dense(const cplx* __restrict__ vals,
                                                            const int* __restrict__ kcol, int RT,
-                                                           int KS, int n, cplx* __restrict__ D) {
+                                                           int KS, int n, cplx* __restrict__ D,
+                                                           const int* __restrict__ colrank,
+                                                           const int* __restrict__ unused) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (item >= RT * KS) return;
   const int rt = item / KS;
   const cplx v = vals[(size_t)item * 64 + lane];
+  int c = kcol[item];
+  if (colrank) c = colrank[c >> 4] * 16 + (c & 15);
   if (v.x != 0.0 || v.y != 0.0)   // padding k-steps repeat column 0 with zero values
-    D[((size_t)rt * 16 + (lane & 15)) * n + kcol[item] + (lane >> 4)] = v;
+    D[((size_t)rt * 16 + (lane & 15)) * n + c + (lane >> 4)] = v;
 }
 
-// dense row-major [n][n] -> MFMA block-row form with every 4-column group (KS = n/4)
+// dense row-major [n][n] -> MFMA block-row form with every 4-column group (KS = n/4).
+// colsite (optional): dense column tile t stands for the level's site tile colsite[t]
 __global__ __launch_bounds__(SW_BLOCK) void k_dense_to_bsr(const cplx* __restrict__ D, int n,
                                                            cplx* __restrict__ vals,
-                                                           int* __restrict__ kcol) {
+                                                           int* __restrict__ kcol,
+                                                           const int* __restrict__ colsite) {
   const int lane = threadIdx.x & 63;
   const int KS = n >> 2;
   const size_t item = (size_t)blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (item >= (size_t)(n >> 4) * KS) return;
   const int rt = (int)(item / KS), ks = (int)(item - (size_t)rt * KS);
   vals[item * 64 + lane] = D[((size_t)rt * 16 + (lane & 15)) * n + 4 * ks + (lane >> 4)];
-  if (lane == 0) kcol[item] = 4 * ks;
+  if (lane == 0) kcol[item] = colsite ? colsite[ks >> 2] * 16 + 4 * (ks & 3) : 4 * ks;
+}
+
+// W[r][col] *= 1 / sqrt(nrm2[col].x)   (0 where the norm vanishes): normalisation of a basis vector
+__global__ __launch_bounds__(SW_BLOCK) void k_colscale(cplx* __restrict__ W, const cplx* __restrict__ nrm2,
+                                                       int n, int nbp) {
+  const int lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const double q = nrm2[col].x;
+  const double sc = q > 0.0 ? 1.0 / sqrt(q) : 0.0;
+  for (int r = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6); r < n; r += gridDim.x * SW_WAVES_PER_BLOCK) {
+    const size_t off = (size_t)r * nbp + col;
+    const cplx v = W[off];
+    W[off] = cmake(sc * v.x, sc * v.y);
+  }
+}
+
+// Y[rows of tile tmap[rt]] = X[same rows] for rt < RT (Y zeroed by the caller): restriction of a level
+// vector to the site tiles a subset operator acts on
+__global__ __launch_bounds__(SW_BLOCK) void k_copy_tiles(const cplx* __restrict__ X, const int* __restrict__ tmap,
+                                                         int RT, int nbp, cplx* __restrict__ Y) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);   // (rt, row in tile)
+  if (item >= RT * 16) return;
+  const size_t row = (size_t)tmap[item >> 4] * 16 + (item & 15);
+  for (int c = lane; c < nbp; c += 64) Y[row * nbp + c] = X[row * nbp + c];
 }
 
 // deterministic pseudo-random start vectors (splitmix64 of (seed, row, column)), entries in [-1,1)^2
@@ -1734,172 +2081,6 @@ __global__ __launch_bounds__(SW_BLOCK) void k_fill_random(cplx* __restrict__ V, 
   const double re = (double)(z & 0xffffffffull) / 2147483648.0 - 1.0;
   const double im = (double)(z >> 32) / 2147483648.0 - 1.0;
   V[(size_t)row * nbp + col] = (col < ncols) ? cmake(re, im) : cmake(0.0, 0.0);
-}
-
-// ------------------------------------------------------------------------------------------
-// Per-probe scalar kernels of the batched flexible GMRES (one thread per probe).
-// Storage: H [(m+1)][m][nbp], cs [m][nbp] (.x), sn [m][nbp], g [(m+1)][nbp].
-// ------------------------------------------------------------------------------------------
-struct FgScalars {
-  cplx* H;
-  cplx* cs;
-  cplx* sn;
-  cplx* g;
-  cplx* y;        // [m][nbp]
-  cplx* normb;    // [nbp] .x
-  cplx* relres;   // [nbp] .x
-  cplx* svec;     // [(m+1)][nbp] .x: scale of basis vector k, v_k = svec_k * vtilde_k (0: frozen)
-  cplx* ys;       // [m][nbp] y_k * svec_k: coefficients of the update x += sum_k ys_k ztilde_k
-  int* iters;     // [nbp] iteration at which the probe first met tol (-1: not yet)
-  int* notconv;   // [1] number of probes still above tol
-  int m;
-  int nbp;
-};
-
-// start of a cycle: beta = sqrt(d[col].x);  first cycle also fixes normb
-__global__ void k_fg_begin(FgScalars s, const cplx* __restrict__ d, int first_cycle, double tol) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= s.nbp) return;
-  const double beta = sqrt(fmax(d[col].x, 0.0));
-  if (first_cycle) {
-    s.normb[col] = cmake(beta, 0.0);
-    s.iters[col] = (beta > 0.0) ? -1 : 0;
-    s.relres[col] = cmake(beta > 0.0 ? 1.0 : 0.0, 0.0);
-  }
-  s.g[col] = cmake(beta, 0.0);
-  s.svec[col] = cmake(beta > 0.0 ? 1.0 / beta : 0.0, 0.0);   // vtilde_0 = r itself
-}
-
-// Column j of the Hessenberg matrix.  The Krylov basis is kept UNNORMALISED in memory: the stored
-// vtilde_k and the true orthonormal v_k differ by a per-probe scale, v_k = svec_k vtilde_k (vtilde_0
-// is the residual itself, vtilde_{k+1} the orthogonalised A M vtilde_k as multiaxpy leaves it), so no
-// pass over the vectors is spent on normalisation; the multigrid cycle and A are linear, so
-// ztilde_k = M vtilde_k and z_k = svec_k ztilde_k.  With the raw dots d_k = vtilde_k^H (A ztilde_j)
-// (d1 + d2: two Gram-Schmidt passes) and nrm2 = |vtilde_{j+1}|^2:
-//   h_{k,j} = svec_k svec_j d_k,   h_{j+1,j} = svec_j sqrt(nrm2),   svec_{j+1} = 1/sqrt(nrm2)
-// (the orthogonalisation coefficients svec_k^2 d_k come from k_reduce_partials).
-__global__ void k_fg_hess(FgScalars s, int j, const cplx* __restrict__ h1,
-                          const cplx* __restrict__ h2, const cplx* __restrict__ nrm2, double tol,
-                          int iter_base, int pyth) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= s.nbp) return;
-  const int m = s.m, nbp = s.nbp;
-  const double sj = s.svec[(size_t)j * nbp + col].x;
-  // apply the previous rotations
-  const double s0 = s.svec[col].x * sj;
-  cplx hk = h2 ? cadd(h1[col], h2[col]) : h1[col];     // h2 == NULL: one Gram-Schmidt pass
-  hk = cmake(s0 * hk.x, s0 * hk.y);
-  double hcol2 = hk.x * hk.x + hk.y * hk.y;      // |h_{0..j,j}|^2 before the rotations
-  for (int k = 0; k < j; ++k) {
-    const double sk1 = s.svec[(size_t)(k + 1) * nbp + col].x * sj;
-    cplx hk1 = h1[(size_t)(k + 1) * nbp + col];
-    if (h2) hk1 = cadd(hk1, h2[(size_t)(k + 1) * nbp + col]);
-    hk1 = cmake(sk1 * hk1.x, sk1 * hk1.y);
-    hcol2 = fma(hk1.x, hk1.x, fma(hk1.y, hk1.y, hcol2));
-    const double c = s.cs[(size_t)k * nbp + col].x;
-    const cplx sn = s.sn[(size_t)k * nbp + col];
-    // [ c  sn ; -conj(sn)  c ]
-    cplx t = cmake(c * hk.x, c * hk.y);
-    cfma(t, sn, hk1);
-    cplx u = cmake(c * hk1.x, c * hk1.y);
-    cfma(u, cmake(-sn.x, sn.y), hk);
-    s.H[((size_t)k * m + j) * nbp + col] = t;
-    hk = u;
-  }
-  // h_{j+1,j} = hn.  pyth == 0: nrm2 = |vtilde_{j+1}|^2 of the orthogonalised vector.  pyth == 1
-  // (last step of a restart cycle, whose vtilde_{j+1} is never used and therefore never formed):
-  // nrm2 = |A ztilde_j|^2 BEFORE the orthogonalisation, and with one classical Gram-Schmidt pass
-  // |h_{j+1,j}|^2 = svec_j^2 |A ztilde_j|^2 - sum_k |h_{k,j}|^2; a remainder below 1e-12 of the
-  // total is round-off of that subtraction and counts as breakdown (the solve is then settled by
-  // the true-residual verification)
-  double wn, hn;
-  if (pyth) {
-    const double tot = sj * sj * fmax(nrm2[col].x, 0.0);
-    double h2v = tot - hcol2;
-    if (!(h2v > 1.0e-12 * tot)) h2v = 0.0;
-    hn = sqrt(h2v);
-    wn = (sj > 0.0) ? hn / sj : 0.0;
-  } else {
-    wn = sqrt(fmax(nrm2[col].x, 0.0));
-    hn = sj * wn;
-  }
-  // new rotation annihilating h_{j+1,j} = hn
-  const double habs = sqrt(hk.x * hk.x + hk.y * hk.y);
-  const double dnm = sqrt(habs * habs + hn * hn);
-  double c;
-  cplx sn;
-  if (dnm == 0.0) {
-    c = 1.0;
-    sn = cmake(0.0, 0.0);
-  } else if (habs == 0.0) {
-    c = 0.0;
-    sn = cmake(1.0, 0.0);
-  } else {
-    c = habs / dnm;
-    const double f = hn / (habs * dnm);
-    sn = cmake(hk.x * f, hk.y * f);  // (a/|a|) * conj(b)/d, b = hn real
-  }
-  s.cs[(size_t)j * nbp + col] = cmake(c, 0.0);
-  s.sn[(size_t)j * nbp + col] = sn;
-  cplx hjj = cmake(c * hk.x, c * hk.y);
-  cfma(hjj, sn, cmake(hn, 0.0));
-  s.H[((size_t)j * m + j) * nbp + col] = hjj;
-  const cplx gj = s.g[(size_t)j * nbp + col];
-  s.g[(size_t)(j + 1) * nbp + col] = cmul(cmake(-sn.x, sn.y), gj);
-  s.g[(size_t)j * nbp + col] = cmake(c * gj.x, c * gj.y);
-  const cplx gn = s.g[(size_t)(j + 1) * nbp + col];
-  const double nb_ = s.normb[col].x;
-  const double rr = (nb_ > 0.0) ? sqrt(gn.x * gn.x + gn.y * gn.y) / nb_ : 0.0;
-  const bool dead = (hn == 0.0 && hcol2 == 0.0);     // frozen earlier: w = 0, rr is meaningless
-  if (!dead) s.relres[col] = cmake(rr, 0.0);
-  if (s.iters[col] < 0) {
-    if (rr < tol) s.iters[col] = iter_base + j + 1;
-    else atomicAdd(s.notconv, 1);
-  }
-  // Next basis vector v_{j+1} = w / h_{j+1,j}.  Probes that have met tol keep iterating in
-  // lockstep with the batch (free extra accuracy) until they are two orders below it; then, or at
-  // (happy) breakdown h_{j+1,j} <= 1e-14 |A z_j| where the remainder is round-off that 1/h would
-  // blow up to a unit vector, the probe is FROZEN: scale 0 makes v_{j+1}, hence z, w and every
-  // later Hessenberg column of this probe exactly zero, and k_fg_solve gives y = 0 for them.
-  const bool frozen = (s.iters[col] >= 0 && rr < 1.0e-2 * tol) ||
-                      (hn * hn <= 1.0e-28 * (hcol2 + hn * hn));
-  s.svec[(size_t)(j + 1) * nbp + col] = cmake((hn > 0.0 && !frozen) ? 1.0 / wn : 0.0, 0.0);
-}
-
-// true-residual check after a solve: d[col].x = ||b - A x||^2; probes above tol are counted and
-// lose their recorded iteration (it is set again when they converge in a later cycle)
-__global__ void k_fg_verify(FgScalars s, const cplx* __restrict__ d, double tol) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= s.nbp) return;
-  const double nb_ = s.normb[col].x;
-  const double rr = (nb_ > 0.0) ? sqrt(fmax(d[col].x, 0.0)) / nb_ : 0.0;
-  s.relres[col] = cmake(rr, 0.0);
-  if (rr >= tol) {
-    s.iters[col] = -1;
-    atomicAdd(s.notconv, 1);
-  }
-}
-
-// y = H(0:k,0:k)^-1 g(0:k) per probe
-__global__ void k_fg_solve(FgScalars s, int k) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= s.nbp) return;
-  const int m = s.m, nbp = s.nbp;
-  for (int i = k - 1; i >= 0; --i) {
-    cplx t = s.g[(size_t)i * nbp + col];
-    for (int l = i + 1; l < k; ++l) {
-      const cplx hl = s.H[((size_t)i * m + l) * nbp + col];
-      const cplx yl = s.y[(size_t)l * nbp + col];
-      cfma(t, cmake(-hl.x, -hl.y), yl);
-    }
-    const cplx hii = s.H[((size_t)i * m + i) * nbp + col];
-    const double dd = hii.x * hii.x + hii.y * hii.y;
-    cplx yi = cmake(0.0, 0.0);
-    if (dd > 0.0) yi = cmake((t.x * hii.x + t.y * hii.y) / dd, (t.y * hii.x - t.x * hii.y) / dd);
-    s.y[(size_t)i * nbp + col] = yi;
-    const double si = s.svec[(size_t)i * nbp + col].x;
-    s.ys[(size_t)i * nbp + col] = cmake(si * yi.x, si * yi.y);
-  }
 }
 
 // MR step length alpha = <T,R>/<T,T> from d0 = <R,T> (= sum conj(R) T), d1 = <T,T>

@@ -89,6 +89,10 @@ def set_params(example_name):
 def _launch(example_name, driver):
     params = set_params(example_name)
     params['function_tol'] = _FUNCTION_TOL
+    # build-only key: concurrent probe batches per GPU (engine handles = HIP streams).  Three on the
+    # 128^2 lattice (a few GB of workspace each), one on the 16^2 toy problem; SW_ENGINES overrides.
+    import os
+    params.setdefault('engines', int(os.environ.get("SW_ENGINES", 3 if example_name == 'schwinger128' else 1)))
     return driver(params)
 
 

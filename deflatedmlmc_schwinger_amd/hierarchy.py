@@ -259,13 +259,29 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
 # ---------------------------------------------------------------------------------------
 # solver hierarchy (level-0 preconditioner only)
 # ---------------------------------------------------------------------------------------
+def weights_from_hessenberg(H):
+    """Weights 1/theta_k of the fixed polynomial smoother from the (degree+1) x degree Hessenberg
+    matrix of an Arnoldi run: theta_k are the roots of the GMRES(degree) residual polynomial (harmonic
+    Ritz values), Leja-ordered for stability.  x <- x + w_k (b - A x), k = 0..degree-1."""
+    import scipy.linalg as sla
+    H = np.asarray(H, dtype=np.complex128)
+    degree = H.shape[1]
+    theta = list(sla.eig(H.conj().T @ H, H[:degree, :].conj().T)[0])
+    ordered = [max(theta, key=abs)]
+    theta.remove(ordered[0])
+    while theta:
+        nxt = max(theta, key=lambda t: np.prod([abs(t - o) for o in ordered]))
+        ordered.append(nxt)
+        theta.remove(nxt)
+    return 1.0 / np.array(ordered, dtype=np.complex128)
+
+
 def smoother_weights(A, degree, seed=2024, project=None):
-    """Weights 1/theta_k of a degree-`degree` fixed polynomial smoother for A: theta_k are the
-    roots of the GMRES(degree) residual polynomial (harmonic Ritz values) of a random complex
-    right-hand side, Leja-ordered for stability.  x <- x + w_k (b - A x), k = 0..degree-1.
+    """Weights of a degree-`degree` fixed polynomial smoother for A (weights_from_hessenberg of an
+    Arnoldi run on a random complex right-hand side; the device-built hierarchies run the Arnoldi
+    process on the GPU instead: sw_setup_arnoldi).
     `project` (optional) maps the random start vector to the part of it the smoother is for (e.g.
     v - P R v: what the coarse correction leaves), so the polynomial spends its degree there."""
-    import scipy.linalg as sla
     if degree <= 0:
         return np.zeros(0, dtype=np.complex128)
     n = A.shape[0]
@@ -282,14 +298,7 @@ def smoother_weights(A, degree, seed=2024, project=None):
             w = w - H[i, j] * V[i]
         H[j + 1, j] = np.linalg.norm(w)
         V.append(w / H[j + 1, j])
-    theta = list(sla.eig(H.conj().T @ H, H[:degree, :].conj().T)[0])
-    ordered = [max(theta, key=abs)]
-    theta.remove(ordered[0])
-    while theta:
-        nxt = max(theta, key=lambda t: np.prod([abs(t - o) for o in ordered]))
-        ordered.append(nxt)
-        theta.remove(nxt)
-    return 1.0 / np.array(ordered, dtype=np.complex128)
+    return weights_from_hessenberg(H)
 
 
 def schur_complement(A, L):
@@ -616,6 +625,28 @@ TUNED_SOLVER_CFG_128 = {
 }
 # cfg["eo_smoother"] = True: the post-smoothing steps of level 0 (cycle[0][1] of them) run on the
 # even-odd Schur complement (sw_set_eo_smoother) instead of the full operator.
+
+
+def synthetic_solver_cfg(L, nu0=10, setup="device"):
+    """Solver hierarchy for a synthetic L x L lattice (BASELINE config 5; bench.py --workload synthetic
+    and the full-size GPU test use the same one): 8 x 8 site aggregates once, then 2 x 2 until the
+    coarsest level is 16 x 16 sites (4096 rows); every level smoothed on its even-odd Schur complement
+    (operators built on the device), a 2-step K-cycle around the solve of level 1, plain V-cycle below.
+    1024^2: levels 2097152 / 262144 / 65536 / 16384 / 4096 (profiles/r02_synthetic_lattices.txt)."""
+    a0 = 8 if L % 8 == 0 and L // 8 >= 16 else 4
+    depth = [[a0, 8]]
+    Lc = L // a0
+    while Lc > 16 and Lc % 8 == 0:
+        depth.append([2, 8])
+        Lc //= 2
+    nsm = len(depth)
+    cyc = [[0, nu0, 0]] + [[0, 10 if i == 1 else 8, 2 if i == 1 and i < nsm - 1 else 0]
+                           for i in range(1, nsm)]
+    if nsm > 1:
+        cyc[-1] = [0, 14, 0]
+    return {"coarsening": depth, "cycle": cyc, "smoother": "richardson", "restart": 3,
+            "eo_levels": list(range(nsm)), "setup": setup,
+            "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1}
 
 
 def _site_prolongator(Al, Lf, hd, agg, nvec, tv, fine_level):

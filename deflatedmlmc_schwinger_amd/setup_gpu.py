@@ -271,28 +271,42 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                 eng.set_coarsest_inv(hid, _hier.dense_inverse(eng.level_dense(hid, nl - 1)))
             eng.hier_end(hid)
         with _timed("smoother_polynomials"):
+            on_device = (cfg.get("setup_polynomials", "device") == "device"
+                         and cfg.get("smoother_target", "all") == "all")
+
+            def fit(lv, which, degree, host_op):
+                """weights of `degree` steps for the level operator (which 0) / its Schur complement (1)"""
+                if degree <= 0:
+                    return np.zeros(0, dtype=np.complex128)
+                if on_device:
+                    # Arnoldi on the GPU (sw_setup_arnoldi): the host sees a (degree+1) x degree matrix
+                    return _hier.weights_from_hessenberg(eng.setup_arnoldi(hid, lv, which, degree))
+                proj = None
+                if which == 0 and cfg.get("smoother_target", "all") == "complement":
+                    # polynomial fitted on what the coarse correction leaves: v - P R v
+                    proj = (lambda v, _lv=lv: v - eng.prolong(hid, _lv, eng.restrict(hid, _lv, v)))
+                return _hier.smoother_weights(host_op(), degree, project=proj)
+
             for lv in range(nl - 1):
                 cyc = cfg["cycle"][lv]
                 eng.set_cycle(hid, lv, cyc[0], cyc[1], cyc[2])
                 if cfg.get("smoother", "richardson") == "richardson":
-                    op = _EngineOperator(eng, hid, lv, sizes[lv])
-                    proj = None
-                    if cfg.get("smoother_target", "all") == "complement":
-                        # polynomial fitted on what the coarse correction leaves: v - P R v
-                        proj = (lambda v, _lv=lv: v - eng.prolong(hid, _lv, eng.restrict(hid, _lv, v)))
-                    eng.set_smoother(hid, lv, _hier.smoother_weights(op, cyc[0], project=proj),
-                                     _hier.smoother_weights(op, cyc[1], project=proj))
-                    if lv == 0 and 0 in eo_levels:
-                        eng.set_eo_smoother(hid, 0, _hier.smoother_weights(
-                            _EngineSchur(eng, hid, L, mass), cyc[1]))
-                    elif lv in eo_levels:
+                    eo_here = lv in eo_levels
+                    full_op = (lambda _lv=lv: _EngineOperator(eng, hid, _lv, sizes[_lv]))
+                    # (an even-odd smoothed level never runs its full-operator post-smoother)
+                    eng.set_smoother(hid, lv, fit(lv, 0, cyc[0], full_op),
+                                     fit(lv, 0, 0 if eo_here and on_device else cyc[1], full_op))
+                    if lv == 0 and eo_here:
+                        eng.set_eo_smoother(hid, 0, fit(0, 1, cyc[1],
+                                                        lambda: _EngineSchur(eng, hid, L, mass)))
+                    elif eo_here:
                         Lc_l = geo[lv - 1]["Lc"]
                         if Lc_l >= 8 and cfg.get("setup_eo", "device") == "device":
                             # block level: S, F, G, Hb by batched 16 x 16 algebra on the device, the
                             # polynomial fitted to S through the engine
                             eng.setup_eo_operators(hid, lv, Lc_l)
-                            eng.set_eo_smoother(hid, lv, _hier.smoother_weights(
-                                _EngineBlockSchur(eng, hid, lv, Lc_l), cyc[1]))
+                            eng.set_eo_smoother(hid, lv, fit(
+                                lv, 1, cyc[1], lambda _lv=lv, _Lc=Lc_l: _EngineBlockSchur(eng, hid, _lv, _Lc)))
                         else:
                             # tiny lattices: the operator comes back in block-row form, the four
                             # operators are formed on the host and uploaded
@@ -307,7 +321,11 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
         with _timed("testvectors"):
             its = eng.setup_testvectors(hid, lvl, 8, seed if lvl == 0 else 0, sweeps, tol, maxiter,
                                         False)
-        log.append({"pass": 1, "level": lvl, "n": sizes[lvl], "gmres_iterations": its,
+        # tol = 0: the sweeps are RELAXATION (a fixed number of unpreconditioned GMRES(m) steps that damp
+        # the rough components of the random vectors), not solves; the converged inverse-iteration
+        # solves are those of pass 2, preconditioned by the hierarchy itself
+        log.append({"pass": 1, "level": lvl, "n": sizes[lvl],
+                    ("relaxation_steps" if tol <= 0.0 else "gmres_iterations"): its,
                     "seconds": round(time.time() - t1, 3)})
         g = geo[lvl]
         with _timed("transfer+galerkin"):
@@ -331,8 +349,8 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
             finish()
     # optional: block levels solved exactly in even-odd reduced form (cfg["direct_levels"]): the dense
     # inverse of the level's Schur complement becomes its even-odd operator 4; the Schur steps of that
-    # level and everything below it drop out of the cycle.  (Host LAPACK for now: the operator comes back
-    # in block-row form, S is formed by the batched 16 x 16 construction and inverted.)
+    # level and everything below it drop out of the cycle.  Formed on the device (sw_setup_direct_level);
+    # cfg["setup_direct"] = "host" keeps the LAPACK route for comparison.
     clock["direct_inverse"] = 0.0
     with _timed("direct_inverse"):
         for lv in cfg.get("direct_levels", ()):
@@ -340,6 +358,9 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
             if not (1 <= lv < nl - 1) or lv not in eo_levels:
                 raise Exception("direct_levels: level %d is not an even-odd smoothed block level" % lv)
             Lc_l = geo[lv - 1]["Lc"]
+            if cfg.get("setup_direct", "device") == "device":
+                eng.setup_direct_level(hid, lv)          # S -> dense -> Gauss-Jordan, on the GPU
+                continue
             sb = _hier.site_blocks_from_block_rows(*eng.level_bsr(hid, lv))
             ops = _hier.coarse_schur_blocks(sb[0], sb[1], Lc_l) if sb is not None else None
             if ops is None:

@@ -32,6 +32,35 @@ def _stats(values):
     return avg, dev
 
 
+def first_stop_index(ests, first_new, level_tol, min_index=5):
+    """The first index i >= first_new at which the reference's loop would break,
+    `i >= min_index and dev_i / sqrt(i + 1) < level_tol` with (avg_i, dev_i) = _stats(ests[:i + 1])
+    (stoch_trace.py:143-154 / 394-406), or None -- without the reference's O(N^2) re-evaluation of the
+    statistics per probe: a running-sum screen (one pass, on estimates shifted by a pivot so the
+    variance does not cancel) marks the indices whose error estimate is below level_tol or within a
+    relative 1e-9 of it -- many orders above the screen's rounding error --, and only those are
+    re-evaluated with the reference's own two-pass formula, in order.  Returns (index, avg, dev) of the
+    break, or None when the loop runs on."""
+    ests = np.asarray(ests, dtype=np.complex128)
+    n = ests.size
+    lo = max(int(first_new), int(min_index))
+    if n == 0 or lo >= n:
+        return None
+    pivot = np.mean(ests[:min(n, 64)])
+    d = ests - pivot
+    cnt = np.arange(1, n + 1, dtype=np.float64)
+    m1 = np.cumsum(d) / cnt
+    m2 = np.cumsum(d.real * d.real + d.imag * d.imag) / cnt
+    var = np.maximum(m2 - (m1.real * m1.real + m1.imag * m1.imag), 0.0)
+    err = np.sqrt(var / cnt)
+    cand = np.flatnonzero(err[lo:] < level_tol * (1.0 + 1e-9) + 1e-300) + lo
+    for i in cand:
+        avg, dev = _stats(ests[:i + 1])
+        if dev / sqrt(i + 1) < level_tol:
+            return int(i), avg, dev
+    return None
+
+
 class HostProbes:
     """Probe source for evaluators that take the probes themselves (int8, (k, n)): this rank's
     slice of a round is produced on the host by the C MT19937 stream at its stream positions
@@ -108,16 +137,21 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
         it_f = np.concatenate([it_f, f])
         it_c = np.concatenate([it_c, c])
         rounds += 1
-        for i in range(first_new, ests.size):
-            avg, dev = _stats(ests[:i + 1])
-            err = dev / sqrt(i + 1)
-            if verbose:
+        if verbose:
+            # the reference's per-probe debug prints (stoch_trace.py:150-152): its own O(N^2) loop
+            for i in range(first_new, ests.size):
+                avg, dev = _stats(ests[:i + 1])
+                err = dev / sqrt(i + 1)
                 print(dev)
                 print(err)
                 print(level_tol)
-            if i >= min_index and err < level_tol:
-                stop_index = i
-                break
+                if i >= min_index and err < level_tol:
+                    stop_index = i
+                    break
+        else:
+            hit = first_stop_index(ests, first_new, level_tol, min_index)
+            if hit is not None:
+                stop_index, avg, dev = hit
         if stop_index is not None:
             break
     if stop_index is None:
@@ -128,7 +162,8 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
     entry.jump(k * n)
     np.random.set_state(entry.numpy_state())
     return {"index": stop_index, "avg": avg, "dev": dev, "ests": ests[:k],
-            "iters_fine": it_f[:k], "iters_coarse": it_c[:k], "rounds": rounds}
+            "iters_fine": it_f[:k], "iters_coarse": it_c[:k], "rounds": rounds,
+            "solved": int(ests.size)}
 
 
 def _setup_solver(A, params, announce=True):
@@ -198,10 +233,13 @@ def hutchinson(A, params):
     mg_solver.coarsest_lev_iters[0] = 0
 
     source = DeviceProbes(mg_solver, params, "hutchinson", 0, params.get('probe_type', 'z2'))
-    loop = run_probe_loop(source, N, rough_trace_tol, params['max_nr_ests'], batch,
+    # a round = one batch per engine handle (concurrent HIP streams) per rank
+    loop = run_probe_loop(source, N, rough_trace_tol, params['max_nr_ests'],
+                          batch * max(1, len(_engines(mg_solver))),
                           verbose=bool(params.get('verbose', False)),
                           probe_type=params.get('probe_type', 'z2'))
-    print(" done. Time : " + str(time.time() - t0) + " seconds")
+    loop_s = time.time() - t0
+    print(" done. Time : " + str(loop_s) + " seconds")
 
     function_iters = int(np.sum(loop["iters_fine"]))
     mg_solver.coarsest_lev_iters[0] = function_iters
@@ -219,6 +257,8 @@ def hutchinson(A, params):
     result['ests'] = loop["ests"]
     result['rough_trace'] = rough_trace
     result['level_tol'] = rough_trace_tol
+    result['probe_loop_s'] = loop_s                 # wall clock of the probe loop and what it solved
+    result['probes_solved'] = loop["solved"]        # (whole rounds: >= nr_ests + 1)
     mg_solver.sync_timer()
     print(mg_solver.timer)
     return result
@@ -312,7 +352,8 @@ def mlmc(A, params):
         print("Computing for level " + str(i) + " ...", end='', flush=True)
 
         source = DeviceProbes(mg_solver, params, "mlmc", i, params.get('probe_type', 'z2'))
-        loop = run_probe_loop(source, n_i, level_trace_tol, params['max_nr_ests'], batch,
+        loop = run_probe_loop(source, n_i, level_trace_tol, params['max_nr_ests'],
+                              batch * max(1, len(_engines(mg_solver))),
                               probe_type=params.get('probe_type', 'z2'))
         res = output_params['results']
         res[i]['function_iters'] += int(np.sum(loop["iters_fine"]))
@@ -323,6 +364,8 @@ def mlmc(A, params):
         res[i]['ests_dev'] = loop["dev"]
         res[i]['ests'] = loop["ests"]              # build-only extras
         res[i]['level_tol'] = level_trace_tol
+        res[i]['probe_loop_s'] = time.time() - t0
+        res[i]['probes_solved'] = loop["solved"]
         print(" done. Time : " + str(time.time() - t0) + " seconds")
 
     # coarsest level, computed directly                            stoch_trace.py:418-437

@@ -137,6 +137,17 @@ int sw_get_level_dense(sw_engine* h, int hid, int level, double* dense);
  * with partial pivoting by the engine's own kernels (k_gj_*; n <= 8192), then packed into MFMA block-row
  * form as sw_set_coarsest_inv would (multigrid.py:342-344: np.linalg.inv).  Fails on a singular operator. */
 int sw_setup_invert_coarsest(sw_engine* h, int hid);
+/* The same one level up: the DENSE inverse of a block level's even-odd Schur complement (operator 0 of
+ * sw_setup_eo_operators / sw_set_eo_operator; at most 8192 rows) formed on the device and installed as
+ * that level's even-odd operator 4, with which the cycle solves the level exactly (option "eo_direct")
+ * instead of smoothing it and visiting the levels below (multigrid.py:342-344,413-416 one level up). */
+int sw_setup_direct_level(sw_engine* h, int hid, int level);
+/* Arnoldi relation for the smoother polynomial, on the device: `degree` steps (classical Gram-Schmidt
+ * twice) of the level operator (which = 0) or of its even-odd Schur complement (which = 1) from a
+ * pseudo-random start vector; Hout receives the (degree+1) x degree Hessenberg matrix, row-major
+ * complex128.  The host turns its harmonic Ritz values into the weights of sw_set_smoother /
+ * sw_set_eo_smoother (the tuned stand-in for lgmres(maxiter=2), multigrid.py:393-394). */
+int sw_setup_arnoldi(sw_engine* h, int hid, int level, int which, int degree, uint64_t seed, double* Hout);
 /* Mark the hierarchy complete (allocates level workspaces lazily). */
 int sw_hier_end(sw_engine* h, int hid);
 
@@ -165,6 +176,12 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *                  with it, complex64 Krylov basis per restart cycle; "cgs2" (0) / "inner_cgs2" (0) second
  *                  Gram-Schmidt pass; "pyth_last" (1) last Arnoldi step of a restart cycle without its
  *                  orthogonalisation pass; "verify" (1) true-residual check of every outer solve;
+ *                  "stop_factor" (1) outer solves iterate until every residual is below stop_factor * tol
+ *                  (iteration counts are still reported at tol; 0.1 pins per-probe estimates to 1e-10
+ *                  relative even where they cancel to small numbers); "fused_reduce" (1) inner products
+ *                  completed inside the launch that forms their partial sums, FGMRES scalar updates
+ *                  riding along; "lgmres_aug" (1) LGMRES augmentation vector in the reference-faithful
+ *                  smoother's second cycle;
  *                  "lazy_sync" (1) convergence read-back only near the expected iteration count;
  *                  "dot_blocks" row blocks of the reducing BLAS-1 launches
  *   stencil level: "stencil_spw", "stencil_tile", "stencil_nt" (sites per wave, lattice tile width,

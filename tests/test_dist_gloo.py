@@ -154,3 +154,85 @@ def test_two_ranks_share_setup_operands_and_replay_mlmc_branch():
     assert r0[2] == r1[2]                 # test vectors, P, A, coarsest inverse: byte-identical
     assert r0[3:] == r1[3:]               # MLMC loop: same stop index, stats, values, stream position
     assert r0[3] >= 5 and r0[7] == 2 * (r0[3] + 1)
+
+
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    from deflatedmlmc_schwinger_amd import dist, stoch_trace
+    comm = dist.TorchComm()
+    # (a) contiguous slices of ragged rounds tile the round
+    cover = []
+    for count in (8, 13, 64, 257):
+        lo, hi = comm.my_slice(count)
+        cover.append((count, lo, hi))
+    # (b) the packed all-gather of per-probe results, ragged round (some ranks hold fewer probes)
+    count = 13
+    lo, hi = comm.my_slice(count)
+    idx = np.arange(lo, hi)
+    e, f, c = comm.allgather_probe_results(idx * (1.0 - 2.0j), 100 + idx, 7 * idx, count)
+    ok_gather = (np.array_equal(e, np.arange(count) * (1.0 - 2.0j)) and
+                 np.array_equal(f, 100 + np.arange(count)) and np.array_equal(c, 7 * np.arange(count)))
+    # (c) bench.py's block map: the (rank, stream) blocks of a round tile the probe stream
+    mine = [bench.first_probe(s, world, rank, 3, e_, 256) for s in range(2) for e_ in range(3)]
+    # (d) the probe loop itself with a synthetic evaluator whose estimate encodes the probe's entries
+    n = 96
+
+    def evaluate(probes):
+        # integer arithmetic: exactly the same value for a probe whatever batch it arrives in
+        p = np.asarray(probes, dtype=np.int64)
+        w = (np.arange(n) % 7) - 3
+        return (p * w).sum(axis=1) * (3.0 + 1.0j) + 10.0, np.full(len(p), 2), np.zeros(len(p), dtype=np.int64)
+    np.random.seed(2718)
+    out = stoch_trace.run_probe_loop(evaluate, n, 0.45, 137, 5, comm=comm)
+    q.put((rank, cover, bool(ok_gather), mine, out["index"], complex(out["avg"]), float(out["dev"]),
+           out["ests"].tolist(), int(np.random.randint(1 << 30))))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_partitioning_gather_and_probe_loop():
+    """world size 8 (what the driver's scaling run uses) over gloo on the CPU: slice partitioning of
+    ragged rounds, the packed per-probe all-gather, bench.py's (rank, stream) block map, and the probe
+    loop against the single-process loop -- same stop index, statistics, values and stream position."""
+    sys.path.insert(0, ROOT)
+    from deflatedmlmc_schwinger_amd import dist, stoch_trace
+    n = 96
+
+    def evaluate(probes):
+        # integer arithmetic: exactly the same value for a probe whatever batch it arrives in
+        p = np.asarray(probes, dtype=np.int64)
+        w = (np.arange(n) % 7) - 3
+        return (p * w).sum(axis=1) * (3.0 + 1.0j) + 10.0, np.full(len(p), 2), np.zeros(len(p), dtype=np.int64)
+    np.random.seed(2718)
+    ref = stoch_trace.run_probe_loop(evaluate, n, 0.45, 137, 5, comm=dist.Comm())
+    ref_next = int(np.random.randint(1 << 30))
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for count in (8, 13, 64, 257):
+        spans = sorted((lo, hi) for r in results for (c, lo, hi) in r[1] if c == count)
+        assert spans[0][0] == 0 and spans[-1][1] == count
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))          # contiguous, no overlap
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    assert all(r[2] for r in results)
+    blocks = sorted(b for r in results for b in r[3])
+    assert blocks == [256 * i for i in range(2 * world * 3)]                 # two rounds, no gap, no overlap
+    for r in results:
+        assert r[4] == ref["index"] and r[5] == complex(ref["avg"]) and r[6] == float(ref["dev"])
+        assert np.array_equal(np.array(r[7]), ref["ests"])
+        assert r[8] == ref_next

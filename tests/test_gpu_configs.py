@@ -1,0 +1,320 @@
+"""GPU tests of the BASELINE configurations at their written sizes and of the round-3 engine paths:
+
+* config 5 at full size: the synthetic 1024^2 lattice with bench.py's own five-level device-built
+  hierarchy (size-independent properties: host-recomputed true residuals through the CSR operator,
+  estimates recomputed from the returned solutions, bit-exact probe codes);
+* config 3 as written: 2-level MLMC difference A_0^-1 - P A_c^-1 R on 32768 -> 8192 with the dense
+  8192^2 coarse solve, per probe against the oracle's restatement of utils.py:252-361 with LU solves;
+* hierarchies built from singular-vector test vectors (multigrid.py:159-188) on the GPU;
+* the strict per-probe parity mode (engine option stop_factor), the in-launch reductions
+  (fused_reduce) and the device-side setup pieces (Arnoldi for the smoother polynomials, the dense
+  Schur inverse of a directly solved block level).
+
+Tolerances: floating point complex128; per-probe estimates 1e-10 relative (north star), differences of
+two O(100) numbers relative to the minuend, operator applications 1e-12."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+from deflatedmlmc_schwinger_amd import gateway, hierarchy, matrix, utils  # noqa: E402
+from deflatedmlmc_schwinger_amd.engine import (MODE_HUTCHINSON, MODE_MLMC, MODE_MLMC_SKIP,  # noqa: E402
+                                               ProbeStream)
+from deflatedmlmc_schwinger_amd.multigrid import MG, REF_HID, SOLVER_HID  # noqa: E402
+from oracle import ref_path as rp  # noqa: E402
+
+
+def _rand(shape, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+def _relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def test_config5_full_size_synthetic_1024_lattice():
+    """BASELINE config 5's lattice at its written size: synthetic 1024^2 random U(1) gauge
+    field (seed 2024, sigma 0.204: mean plaquette ~0.92; m = -0.05), 2 097 152 unknowns, the five-level
+    hierarchy bench.py --workload synthetic uses, built on the device.  No LU at this size; instead
+    (i) the probe codes generated on the device are np.random's legacy stream bit for bit,
+    (ii) the TRUE residual of every returned solution, recomputed on the host with the CSR operator
+        assembled from the links, is below 5e-12 (tol 1e-12 on the engine's own residual),
+    (iii) the estimates of the probe driver equal x^H z recomputed on the host from the solutions."""
+    L, mass, nb = 1024, -0.05, 64
+    U1, U2 = matrix.synthetic_links(L, 0.204, 2024)
+    cfg = hierarchy.synthetic_solver_cfg(L)
+    mg = MG((L, mass, U1, U2))
+    mg.setup_solver_only(cfg, device=0, engines=1)
+    assert mg.solver_info["levels"] == [2097152, 262144, 65536, 16384, 4096]
+    eng = mg.engine
+    n = 2 * L * L
+    eng.stream_set(ProbeStream(123456).window())
+    eng.probes_generate(0, 0, nb, 0)
+    eng.probes_select(0)
+    eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
+    ests, itf, _ = eng.hutch_fetch()
+    codes = eng.probes_fetch(0)
+    np.random.seed(123456)
+    ref_codes = (2 * np.random.randint(2, size=(nb, n)) - 1).astype(np.int8)
+    assert np.array_equal(codes, ref_codes)                                  # (i)
+    del ref_codes
+    assert 1 <= itf.min() and itf.max() <= 20, (itf.min(), itf.max())
+    B = codes.astype(np.complex128)
+    X, its, relres = eng.solve(SOLVER_HID, 0, B, 1e-12, 1000)
+    assert relres.max() < 1e-12
+    A = (hierarchy.wilson_from_links(U1, U2, L)
+         + mass * sp.identity(n, dtype=np.complex128, format="csr")).tocsr()
+    worst = 0.0
+    for k0 in range(0, nb, 8):                                               # (ii), 8 columns at a time
+        R = B[k0:k0 + 8].T - A @ X[k0:k0 + 8].T
+        worst = max(worst, float(np.max(np.linalg.norm(R, axis=0) / np.linalg.norm(B[k0:k0 + 8].T, axis=0))))
+    print("1024^2: worst true relative residual %.2e, iterations %d..%d" % (worst, its.min(), its.max()))
+    assert worst < 5e-12
+    e_host = np.einsum("kn,kn->k", B, X)                                     # (iii): probes are real
+    assert np.max(np.abs(e_host - ests) / np.abs(e_host)) < 1e-10
+    # linearity of the stencil at this size (a size-independent property of the operator kernel)
+    Z = _rand((2, n), 5)
+    lhs = eng.apply_dirac(SOLVER_HID, 0, (0.3 - 0.2j) * Z[0] + Z[1])
+    assert _relerr(lhs, A @ ((0.3 - 0.2j) * Z[0] + Z[1])) < 1e-13
+    eng.close()
+
+
+def test_config3_as_written_two_level_mlmc_difference():
+    """BASELINE config 3 literally: schwinger128, a 2-level hierarchy 32768 -> 8192 (the
+    reference's aggregation), the MLMC difference probe e = x^H A_0^-1 C x - x^H P A_c^-1 R C x with the
+    coarse solve done by the dense 8192^2 inverse on the matrix cores, against the oracle's restatement of
+    utils.py:252-361 with sparse-LU solves -- and the direct coarse term tr(Pperm^H A_c^-1 Bblock_perm)
+    (stoch_trace.py:428-435) so that difference + coarse term reproduce the exact trace."""
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    params.update({'max_nr_levels': 2, 'nr_deflat_vctrs': 0})
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    tp['mlmc_deflat_vctrs'] = [0]
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=2, dim=2, acc_eigvs=tp['accuracy_mg_eigvs'],
+             sys_type='schwinger', params=tp)
+    levels = mg.ml.levels
+    assert [lev.A.shape[0] for lev in levels] == [32768, 8192]
+    cinv = np.asarray(mg.coarsest_inv)
+    lu = rp.LUSolver(A)
+    n = A.shape[0]
+    np.random.seed(2468)
+    probes = utils.draw_probes(8, n)
+    ests, itf, itc = mg.engine.hutch_batch(MODE_MLMC, 0, probes, 1e-12, 1000)
+    assert np.all(itc == 1)                          # the coarse "solve" is the dense inverse
+    for k in range(8):
+        x0 = probes[k].astype(np.complex128)
+        ref = rp.mlmc_probe(x0, 0, levels, False, lambda l, b: lu(b), cinv, True)
+        z = lu(levels[0].Bblock_perm @ (levels[0].Pperm.transpose() @ x0))
+        scale = max(abs(np.vdot(x0, z)), abs(ref))
+        assert abs(ests[k] - ref) / scale < 1e-10, (k, ests[k], ref)
+    # The coarse term (stoch_trace.py:428-435) and the telescoping identity of SURVEY 3.1,
+    #   tr[(A_0^-1 - P A_c^-1 R) M_0] + tr[A_c^-1 R M_0 P] = tr[A_0^-1 M_0]  (= gateway.py:104),
+    # with B_1 M_1 = R M_0 P: the mean of 512 difference probes from the GPU plus the direct coarse term
+    # reproduces the reference's "exact trace" comment within the estimator's own error.
+    coarse = np.trace(levels[1].Pperm.transpose().conjugate() @ (cinv @ levels[1].Bblock_perm))
+    G = (levels[0].R @ (levels[0].Pperm.transpose() @ levels[0].P)).toarray()
+    assert abs(coarse - np.sum(cinv * G.T)) < 1e-8 * abs(coarse)
+    np.random.seed(123456)
+    big = utils.draw_probes(512, n)
+    e1, _, _ = mg.engine.hutch_batch(MODE_MLMC, 0, big[:256], 1e-12, 1000)
+    e2, _, _ = mg.engine.hutch_batch(MODE_MLMC, 0, big[256:], 1e-12, 1000)
+    e = np.concatenate([e1, e2])
+    err = np.std(e) / np.sqrt(e.size)
+    total = np.mean(e) + coarse
+    print("config 3: difference %.4f%+.4fj +- %.3f, coarse %.4f%+.4fj, sum %.4f%+.4fj"
+          % (np.mean(e).real, np.mean(e).imag, err, coarse.real, coarse.imag, total.real, total.imag))
+    assert abs(total - gateway.EXACT_TRACE_SCHWINGER128) < 4.0 * err
+    mg.engine.close()
+
+
+@pytest.mark.parametrize("name,tv_type", [("schwinger16", "LSVs"), ("schwinger16", "RSVs"),
+                                          ("schwinger128", "LSVs"), ("schwinger128", "RSVs")])
+def test_singular_vector_hierarchies_run_on_the_gpu(name, tv_type):
+    """hierarchies built from singular-vector test vectors (test_vectors_type 'LSVs' /
+    'RSVs', multigrid.py:159-188) uploaded to the engine: eight MLMC level-0 difference probes each
+    against the oracle's probe body with LU solves on the same hierarchy, 1e-10."""
+    params = gateway.set_params(name)
+    params['function_tol'] = 1e-12
+    params['test_vectors_type'] = tv_type
+    params['accuracy_mg_eigvs'] = 'high'
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    tp['mlmc_deflat_vctrs'] = [0] * 3
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs='high', sys_type='schwinger', params=tp)
+    levels = mg.ml.levels
+    nlev = len(levels)
+    assert nlev >= 3
+    cinv = np.asarray(mg.coarsest_inv)
+    lus = {}
+
+    def solve_level(l, b):
+        if l not in lus:
+            lus[l] = rp.LUSolver(levels[l].A)
+        return lus[l](b)
+
+    n = A.shape[0]
+    use_perm = bool(tp['use_permuted'])
+    skip = nlev >= 4
+    np.random.seed(97)
+    probes = utils.draw_probes(8, n)
+    mode = MODE_MLMC_SKIP if skip else MODE_MLMC
+    ests, itf, itc = mg.engine.hutch_batch(mode, 0, probes, 1e-12, 1000)
+    for k in range(8):
+        x0 = probes[k].astype(np.complex128)
+        ref = rp.mlmc_probe(x0, 0, levels, skip, solve_level, cinv, use_perm)
+        xd = levels[0].Bblock_perm @ (levels[0].Pperm.transpose() @ x0) if use_perm else x0
+        scale = max(abs(np.vdot(x0, solve_level(0, xd))), abs(ref))
+        assert abs(ests[k] - ref) / scale < 1e-10, (name, tv_type, k, ests[k], ref)
+    mg.engine.close()
+
+
+def _tuned128(engines=1, extra=None):
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    params['solver_cfg'] = dict(hierarchy.TUNED_SOLVER_CFG_128, **(extra or {}))
+    params['engines'] = engines
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "hutchinson")
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs=tp['accuracy_mg_eigvs'], sys_type='schwinger', params=tp)
+    return A, tp, mg
+
+
+def test_in_launch_reductions_match_the_two_stage_ones():
+    """engine option fused_reduce: the inner products of the Krylov solver completed inside the launch
+    that forms their partial sums (last block done, two levels), the FGMRES scalar updates riding along.
+    Same solves as with the separate reduction kernels -- same iteration counts, solutions equal to
+    round-off (the order of the partial sums differs between the two) -- and bit-identical results when
+    repeated (the order of every sum is fixed, whichever workgroup does the adding)."""
+    A, tp, mg = _tuned128()
+    eng = mg.engine
+    n = A.shape[0]
+    B = _rand((100, n), 31)                      # two probe chunks, one of them ragged
+    out = {}
+    try:
+        for flag in (1, 0, 1):
+            eng.set_option("fused_reduce", flag)
+            for hid in (SOLVER_HID, REF_HID):    # even-odd reduced FGMRES and the full-system one
+                X, its, rr = eng.solve(hid, 0, B[:100 if hid == SOLVER_HID else 3], 1e-12, 400)
+                assert rr.max() < 1e-12
+                out.setdefault((flag, hid), []).append((X, np.asarray(its)))
+    finally:
+        eng.set_option("fused_reduce", 1)
+    for hid in (SOLVER_HID, REF_HID):
+        (Xa, ia), (Xb, ib) = out[(1, hid)]
+        assert np.array_equal(Xa, Xb) and np.array_equal(ia, ib)            # deterministic
+        Xc, ic = out[(0, hid)][0]
+        assert np.max(np.abs(ia - ic)) <= 1
+        assert _relerr(Xa, Xc) < 1e-10
+    # launch count: a batch must need fewer launches with the reductions folded in
+    eng.timers_reset()
+    eng.solve(SOLVER_HID, 0, B[:64], 1e-12, 400)
+    fused = eng.launch_count()
+    eng.set_option("fused_reduce", 0)
+    eng.timers_reset()
+    eng.solve(SOLVER_HID, 0, B[:64], 1e-12, 400)
+    plain = eng.launch_count()
+    eng.set_option("fused_reduce", 1)
+    print("launches per solve: fused %d, two-stage %d" % (fused, plain))
+    assert fused < plain
+    eng.close()
+
+
+def test_strict_parity_mode_iterates_below_the_reference_tolerance():
+    """engine option stop_factor = 0.1: the batch is iterated until every TRUE residual is below
+    0.1 * tol while the reported iteration counts stay those at tol (the reference's count,
+    multigrid.py:347-366).  Cost: at most one more outer iteration for the batch."""
+    A, tp, mg = _tuned128()
+    eng = mg.engine
+    n = A.shape[0]
+    B = _rand((64, n), 77)
+    X1, it1, rr1 = eng.solve(SOLVER_HID, 0, B, 1e-12, 400)
+    eng.timers_reset()
+    try:
+        eng.set_option("stop_factor", 0.1)
+        X2, it2, rr2 = eng.solve(SOLVER_HID, 0, B, 1e-12, 400)
+    finally:
+        eng.set_option("stop_factor", 1.0)
+    t1 = np.linalg.norm(B.T - A @ X1.T, axis=0) / np.linalg.norm(B.T, axis=0)
+    t2 = np.linalg.norm(B.T - A @ X2.T, axis=0) / np.linalg.norm(B.T, axis=0)
+    print("true residuals: default %.2e, strict %.2e; reported iterations %d / %d"
+          % (t1.max(), t2.max(), it1.max(), it2.max()))
+    assert t1.max() < 5e-12 and t2.max() < 1.5e-13
+    assert rr2.max() < 1e-13
+    assert np.all(np.abs(np.asarray(it2) - np.asarray(it1)) <= 1)          # counts are taken at tol
+    eng.close()
+
+
+def test_device_arnoldi_gives_a_smoother_polynomial_as_good_as_the_hosts():
+    """sw_setup_arnoldi (f2): the Arnoldi relation behind the smoother polynomial computed on the device.
+    The random start vectors differ from the host's, so the weights are not compared entry by entry;
+    checked instead: (i) the Ritz values lie in the operator's numerical range (16^2: dense Hermitian parts),
+    (ii) a polynomial of the device's weights damps a random residual as well as the host-fitted one
+    (within a factor 2), for the level operator and for the even-odd Schur complement."""
+    params = gateway.set_params('schwinger16')
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "hutchinson")
+    tp['solver_cfg'] = dict(hierarchy.DEFAULT_SOLVER_CFG)
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs='high', sys_type='schwinger', params=tp)
+    eng = mg.engine
+    L = 16
+    S, E, O, D = hierarchy.schur_complement(A, L)
+    # the stencil level must carry an even-odd smoother for which = 1 to be defined there
+    for which, M in ((0, sp.csr_matrix(A)), (1, S)):
+        deg = 8
+        H = eng.setup_arnoldi(SOLVER_HID, 0, which, deg)
+        assert H.shape == (deg + 1, deg)
+        assert np.allclose(np.tril(H[:deg, :], -2), 0.0)                      # Hessenberg
+        ritz = np.linalg.eigvals(H[:deg, :])
+        Md = M.toarray()
+        hr = np.linalg.eigvalsh(0.5 * (Md + Md.conj().T))                    # numerical range: real extent
+        hi = np.linalg.eigvalsh(-0.5j * (Md - Md.conj().T))                   # ... imaginary extent
+        assert hr[0] - 1e-9 < ritz.real.min() and ritz.real.max() < hr[-1] + 1e-9
+        assert hi[0] - 1e-9 < ritz.imag.min() and ritz.imag.max() < hi[-1] + 1e-9
+        w_dev = hierarchy.weights_from_hessenberg(H)
+        w_host = hierarchy.smoother_weights(M, deg)
+        r0 = _rand(M.shape[0], 12)
+
+        def damp(w):
+            x = np.zeros_like(r0)
+            for wk in w:
+                x = x + wk * (r0 - M @ x)
+            return np.linalg.norm(r0 - M @ x) / np.linalg.norm(r0)
+        dd, dh = damp(w_dev), damp(w_host)
+        print("which %d: residual after %d steps -- device weights %.3e, host weights %.3e" % (which, deg, dd, dh))
+        assert dd < 2.0 * dh and dd < 1.0
+    eng.close()
+
+
+def test_dense_schur_inverse_built_on_the_device_matches_the_host_route():
+    """sw_setup_direct_level (f2): the dense inverse of the 4096-row level's even-odd Schur complement
+    formed on the device (S -> dense -> Gauss-Jordan -> block rows) against the host LAPACK route
+    (hierarchy.dense_schur_inverse_blocks), applied through the C ABI."""
+    params = gateway.set_params('schwinger128')
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    Lc = 16
+    site = np.arange(Lc * Lc)
+    even = (((site % Lc) + (site // Lc)) & 1) == 0
+    E = np.nonzero(np.repeat(even, 16))[0]
+    X = np.zeros((5, Lc * Lc * 16), dtype=complex)
+    X[:, E] = _rand((5, E.size), 8)
+    res = {}
+    for route in ("device", "host"):
+        mg = MG(A)
+        mg.setup_solver_only(dict(hierarchy.TUNED_SOLVER_CFG_128, direct_levels=[1], setup_direct=route))
+        res[route] = mg.engine.apply_eo_operator(SOLVER_HID, 1, 4, X)
+        if route == "device":
+            Y = mg.engine.apply_eo_operator(SOLVER_HID, 1, 0, res[route])
+            assert _relerr(Y[:, E], X[:, E]) < 1e-11                        # S S^-1 = 1 on the even rows
+        mg.engine.close()
+    assert _relerr(res["device"][:, E], res["host"][:, E]) < 1e-10
+    assert np.abs(np.delete(res["device"], E, axis=1)).max() == 0.0          # odd rows untouched

@@ -141,8 +141,9 @@ def test_benchmarked_path_full_batch_per_probe_parity():
     """What bench.py times, checked probe by probe: the tuned solver hierarchy (32768/4096/1024, built
     on the device, even-odd smoothing on both levels, GMRES(3)), a full batch of 256 probes GENERATED on
     the device at a mid-stream position (the block of rank 1, stream 2, step 1 of a 2-rank run), deflated
-    Hutchinson with k = 8 -- all 256 estimates against the sparse-LU oracle at 1e-10 relative (see the
-    note on near-cancelling estimates below), the
+    Hutchinson with k = 8 -- all 256 estimates against the sparse-LU oracle at 1e-10 relative: strictly,
+    for every probe, in the engine's parity mode (stop_factor = 0.1), and with the floor for
+    near-cancelling estimates noted below at the reference's own stopping point (the default); the
     probe codes bit for bit against np.random's legacy stream, and the same batch uploaded from the
     host giving the same estimates."""
     from deflatedmlmc_schwinger_amd import hierarchy
@@ -193,3 +194,20 @@ def test_benchmarked_path_full_batch_per_probe_parity():
     assert np.all(rel[np.abs(refs) >= floor] < 1e-10), detail
     assert np.mean(rel < 1e-10) >= 0.99, detail
     assert 1 <= itf.min() and itf.max() <= 14, (itf.min(), itf.max())
+    # STRICT parity mode (engine option stop_factor = 0.1, SURVEY section 7 "solve to 1e-13"): the same
+    # batch iterated until every true residual is below 0.1 * tol -- the north star's criterion as
+    # written, 1e-10 relative for EVERY one of the 256 probes, near-cancelling estimates included.
+    # Reported iteration counts stay those at tol; the cost is at most one more outer iteration.
+    try:
+        eng.set_option("stop_factor", 0.1)
+        eng.probes_select(0)
+        eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
+        ests_s, itf_s, _ = eng.hutch_fetch()
+    finally:
+        eng.set_option("stop_factor", 1.0)
+    rel_s = np.abs(ests_s - refs) / np.abs(refs)
+    worst = int(np.argmax(rel_s))
+    print("strict mode: max rel %.3e (probe %d, |ref| %.2f); iteration counts at tol %d..%d (default %d..%d)"
+          % (rel_s.max(), worst, abs(refs[worst]), itf_s.min(), itf_s.max(), itf.min(), itf.max()))
+    assert rel_s.max() < 1e-10, (worst, float(rel_s.max()), float(abs(refs[worst])))
+    assert np.all(np.abs(itf_s.astype(int) - itf.astype(int)) <= 1)

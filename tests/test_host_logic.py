@@ -524,3 +524,42 @@ def test_dense_schur_inverse_in_block_row_form_inverts_the_schur_operator():
     prod[np.ix_(Er, Er)] = 0
     assert abs(prod).max() == 0
     assert kcol.shape == (ns // 2, 4 * (ns // 2)) and vals.shape == (ns // 2, 4 * (ns // 2), 64)
+
+
+def test_screened_stopping_rule_equals_the_reference_replay():
+    """stoch_trace.first_stop_index (running-sum screen + exact re-evaluation of the candidates)
+    against the reference's own O(N^2) loop (oracle restatement of stoch_trace.py:137-154): identical
+    stop index, mean and deviation -- on 10^5 synthetic estimates with the statistics of the 128^2
+    deflated estimator (mean ~ -7+6j, deviation ~ 140), on borderline tolerances, on sequences with a
+    large offset (where a one-pass variance would cancel) and on rounds that resume mid-sequence."""
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    from oracle import ref_path as rp
+    rng = np.random.default_rng(99)
+    big = (-7.0 + 6.0j) + 100.0 * (rng.standard_normal(100000) + 1j * rng.standard_normal(100000))
+    # a tolerance reached about a third of the way in: 141 / sqrt(i + 1) < tol  =>  i ~ 3.2e4
+    tol = 0.79
+    i_ref, avg_ref, dev_ref = rp.stopping_rule(big[:40000], tol)
+    assert 20000 < i_ref < 39999
+    hit = stoch_trace.first_stop_index(big, 0, tol)
+    assert hit is not None and hit[0] == i_ref and hit[1] == avg_ref and hit[2] == dev_ref
+    # resumed rounds: scanning from first_new on finds the same index; beyond it, the next one
+    assert stoch_trace.first_stop_index(big, i_ref - 100, tol)[0] == i_ref
+    assert stoch_trace.first_stop_index(big[:i_ref], 0, tol) is None
+    # never reached
+    assert stoch_trace.first_stop_index(big, 0, 1e-3) is None
+    # many short sequences, tolerances placed exactly ON the error estimate of some index (borderline)
+    for trial in range(200):
+        n = int(rng.integers(6, 400))
+        off = (10.0 ** rng.integers(0, 9)) * (1.0 + 0.5j) if trial % 3 == 0 else 0.0
+        e = off + rng.standard_normal(n) * (1.0 + rng.random()) + 1j * rng.standard_normal(n)
+        k = int(rng.integers(5, n))
+        cur = e[:k + 1]
+        dev = np.sqrt(np.sum(np.abs(cur - np.sum(cur) / (k + 1)) ** 2) / (k + 1))
+        for tol_t in (dev / np.sqrt(k + 1), np.nextafter(dev / np.sqrt(k + 1), np.inf), 0.3, 0.05):
+            i_ref, avg_ref, dev_ref = rp.stopping_rule(e, tol_t)
+            stopped = i_ref < n - 1 or (dev_ref / np.sqrt(n) < tol_t and n - 1 >= 5)
+            hit = stoch_trace.first_stop_index(e, 0, tol_t)
+            if stopped:
+                assert hit is not None and hit[0] == i_ref and hit[1] == avg_ref and hit[2] == dev_ref, trial
+            else:
+                assert hit is None, trial

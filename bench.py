@@ -225,18 +225,29 @@ def run(args):
     def block_start(s, e):
         return first_probe(s, world, rank, ne, e, nb)
 
-    def run_one(e, s, generate=True, slot=0):
+    gen_ready = [None] * ne      # step whose probes engine e already holds in slot (step & 1)
+
+    def run_one(e, s, generate=True, slot=0, prefetch=False):
+        """One batch on engine e.  generate: its probes are drawn on the device, into slot (s & 1) --
+        unless the previous step already queued them there (prefetch: the engine's generation stream
+        draws step s + 1's probes while step s is being solved; EXACTLY one generation per timed step
+        stays inside the timed region, see headline())."""
         if generate:
-            engs[e].probes_generate(slot, 0, nb, block_start(s, e) * n)
+            slot = s & 1
+            if gen_ready[e] != s:
+                engs[e].probes_generate(slot, 0, nb, block_start(s, e) * n)
+            if prefetch:
+                engs[e].probes_generate(1 - slot, 0, nb, block_start(s + 1, e) * n)
+                gen_ready[e] = s + 1
         engs[e].probes_select(slot)
         engs[e].hutch_run(run_mode, 0, args.tol, maxiter)
         return engs[e].hutch_fetch()
 
-    def step(s, generate=True, slot=0):
+    def step(s, generate=True, slot=0, prefetch=False):
         if ne == 1:
-            res = [run_one(0, s, generate, slot)]
+            res = [run_one(0, s, generate, slot, prefetch)]
         else:
-            res = list(pool.map(lambda e: run_one(e, s, generate, slot), range(ne)))
+            res = list(pool.map(lambda e: run_one(e, s, generate, slot, prefetch), range(ne)))
         ests = np.concatenate([r[0] for r in res])
         itf = np.concatenate([r[1] for r in res])
         stats = comm.allreduce_stats(swdist.local_stats(ests))
@@ -264,8 +275,11 @@ def run(args):
     iters_seen = []
 
     def headline():
-        for s in range(args.warmup, args.warmup + args.steps):
-            ests, itf, stats = step(s)
+        last = args.warmup + args.steps - 1
+        for s in range(args.warmup, last + 1):
+            # step s + 1's probes are drawn during step s; the first timed step draws its own (the
+            # warm-up did not prefetch them) and the last one prefetches nothing: K generations in K steps
+            ests, itf, stats = step(s, prefetch=(s < last))
             total[:] += stats
             iters_seen.append(int(itf.max()))
     elapsed = timed(headline)
@@ -275,15 +289,17 @@ def run(args):
     nres = min(args.steps, 8)
     for i in range(nres):
         for e in range(ne):
-            engs[e].probes_generate(1 + i, 0, nb, block_start(args.warmup + i, e) * n)
-    elapsed_resident = timed(lambda: [step(args.warmup + i, False, 1 + i) for i in range(nres)])
+            engs[e].probes_generate(2 + i, 0, nb, block_start(args.warmup + i, e) * n)
+    for e in range(ne):
+        engs[e].sync()
+    elapsed_resident = timed(lambda: [step(args.warmup + i, False, 2 + i) for i in range(nres)])
     host_batches = [ProbeStream(7 + e).rademacher(nb, n) for e in range(ne)]
 
     def pcie():
         for i in range(nres):
             for e in range(ne):
-                engs[e].probes_upload_slot(1 + i, 0, host_batches[e])
-            step(args.warmup + i, False, 1 + i)
+                engs[e].probes_upload_slot(2 + i, 0, host_batches[e])
+            step(args.warmup + i, False, 2 + i)
     elapsed_pcie = timed(pcie)
 
     # ---- secondary: the same K steps with the multigrid cycle in single precision (complex64 on the

@@ -164,6 +164,10 @@ struct EventRec {
 struct sw_engine {
   int device = 0;
   hipStream_t stream = nullptr;
+  // probe generation runs on a stream of its own, so that the next batch's probes are drawn while the
+  // current batch is being solved (sw_probes_generate is asynchronous; sw_hutch_run waits for its slot)
+  hipStream_t gen_stream = nullptr;
+  int pb_slot = -1;
   std::string err;
   Hier hier[SW_MAX_HIER];
   int restart = 24;
@@ -236,6 +240,8 @@ struct sw_engine {
     int8_t* p = nullptr;
     size_t bytes = 0;
     int level = -1, nb = 0;
+    hipEvent_t ready = nullptr;   // recorded on gen_stream behind the slot's generation (pending: true)
+    bool pending = false;
   };
   std::vector<ProbeSlot> slots;
   // device probe stream (k_mt_jump / k_mt_generate): window = 624 raw MT19937 words at mt_pos
@@ -1916,7 +1922,7 @@ int sw_create(sw_engine** out, int device_id) {
     delete h;
     return sw_fail(nullptr, "hipSetDevice(%d) failed", device_id);
   }
-  if (hipStreamCreate(&h->stream) != hipSuccess) {
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->gen_stream) != hipSuccess) {
     delete h;
     return sw_fail(nullptr, "hipStreamCreate failed");
   }
@@ -1939,6 +1945,9 @@ int sw_destroy(sw_engine* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->gen_stream) (void)hipStreamSynchronize(h->gen_stream);
+  for (auto& sl : h->slots)
+    if (sl.ready) (void)hipEventDestroy(sl.ready);
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   for (auto& a : h->allocs) (void)hipFree(a.first);
   for (auto& r : h->recs) {
@@ -1950,6 +1959,7 @@ int sw_destroy(sw_engine* h) {
   if (h->d_tick) (void)hipFree(h->d_tick);
   if (h->h_notconv) (void)hipHostFree(h->h_notconv);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->gen_stream) (void)hipStreamDestroy(h->gen_stream);
   delete h;
   return 0;
 }
@@ -2001,8 +2011,13 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
       h->perm_src[l] = nullptr;
       SWCHK(free_op(h, h->rhsmap[l]));
     }
-    for (auto& sl : h->slots) SWCHK(dev_free(h, sl.p));
+    HIPCHK(hipStreamSynchronize(h->gen_stream));
+    for (auto& sl : h->slots) {
+      SWCHK(dev_free(h, sl.p));
+      if (sl.ready) (void)hipEventDestroy(sl.ready);
+    }
     h->slots.clear();
+    h->pb_slot = -1;
     h->pb_probes = nullptr;
     h->pb_level = -1;
     h->pb_nb = h->pb_nbp = 0;
@@ -3606,6 +3621,10 @@ int sw_probes_upload_slot(sw_engine* h, int slot, int level, int nb, const int8_
   const size_t bytes = (size_t)nb * lv.n;
   if ((int)h->slots.size() <= slot) h->slots.resize(slot + 1);
   sw_engine::ProbeSlot& sl = h->slots[slot];
+  if (sl.pending) {
+    HIPCHK(hipStreamSynchronize(h->gen_stream));
+    sl.pending = false;
+  }
   if (sl.bytes < bytes) {
     SWCHK(dev_free(h, sl.p));
     sl.p = nullptr;
@@ -3625,6 +3644,7 @@ int sw_probes_select(sw_engine* h, int slot) {
   if (!h) return 1;
   if (slot < 0 || slot >= (int)h->slots.size() || !h->slots[slot].p)
     return sw_fail(h, "probe slot %d is empty", slot);
+  h->pb_slot = slot;
   h->pb_probes = h->slots[slot].p;
   h->pb_level = h->slots[slot].level;
   h->pb_nb = h->slots[slot].nb;
@@ -3642,6 +3662,7 @@ int sw_probes_stream_set(sw_engine* h, const uint32_t* window) {
   if (!h) return 1;
   if (!window) return sw_fail(h, "null MT19937 window");
   HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->gen_stream));      // a queued generation may still read the old window
   if (!h->mt_win0) SWCHK(dev_realloc(h, &h->mt_win0, (size_t)SW_MT_N));
   if (!h->mt_win) SWCHK(dev_realloc(h, &h->mt_win, (size_t)2 * SW_MT_N));
   if (!h->mt_poly) SWCHK(dev_realloc(h, &h->mt_poly, (size_t)SW_MT_N));
@@ -3671,10 +3692,14 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
   const int n = lv.n;
   if (n % 4) return sw_fail(h, "device probe generation needs n %% 4 == 0 (n = %d)", n);
   const uint64_t total = (uint64_t)nb * (uint64_t)n;
+  // Asynchronous, on the generation stream: the call returns once the work is queued, the slot's `ready`
+  // event orders it ahead of the sw_hutch_run that consumes the slot.  (While profiling, generation
+  // stays on the solve stream so that the per-launch event pairs bracket it.)
+  hipStream_t gs = h->profiling ? h->stream : h->gen_stream;
   // 1. move the resident window to `pos`
   if (pos < h->mt_pos) {
     HIPCHK(hipMemcpyAsync(h->mt_win + (size_t)SW_MT_N * h->mt_cur, h->mt_win0,
-                          SW_MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+                          SW_MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
     h->mt_pos = 0;
   }
   if (pos > h->mt_pos) {
@@ -3683,12 +3708,12 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
       uint32_t poly[SW_MT_N];
       if (sw_mt_jump_poly(dist, poly) != 0) return sw_fail(h, "jump polynomial construction failed");
       // the previous polynomial may still be in use by a queued k_mt_jump: stream order protects it
-      HIPCHK(hipMemcpyAsync(h->mt_poly, poly, sizeof poly, hipMemcpyHostToDevice, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));   // `poly` is a stack buffer
+      HIPCHK(hipMemcpyAsync(h->mt_poly, poly, sizeof poly, hipMemcpyHostToDevice, gs));
+      HIPCHK(hipStreamSynchronize(gs));   // `poly` is a stack buffer
       h->mt_dist = dist;
     }
     LaunchScope ls(h, T_OTHER);
-    hipLaunchKernelGGL(swk::k_mt_jump, dim3(1), dim3(SW_MT_BLOCK), 0, h->stream,
+    hipLaunchKernelGGL(swk::k_mt_jump, dim3(1), dim3(SW_MT_BLOCK), 0, gs,
                        (const uint32_t*)(h->mt_win + (size_t)SW_MT_N * h->mt_cur),
                        (const uint32_t*)h->mt_poly, h->mt_win + (size_t)SW_MT_N * (1 - h->mt_cur));
     KLAUNCH_CHECK();
@@ -3705,6 +3730,7 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
       if (sw_mt_jump_poly((uint64_t)s * segdraws, &fam[(size_t)(s - 1) * SW_MT_N]) != 0)
         return sw_fail(h, "jump polynomial construction failed");
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->gen_stream));
     SWCHK(upload(h, &h->mt_family, fam.data(), fam.size()));
     h->mt_fam_seg = segdraws;
     h->mt_fam_count = S - 1;
@@ -3714,6 +3740,7 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
   sw_engine::ProbeSlot& sl = h->slots[slot];
   if (sl.bytes < total) {
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->gen_stream));
     SWCHK(dev_free(h, sl.p));
     sl.p = nullptr;
     void* q;
@@ -3723,7 +3750,7 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
   }
   {
     LaunchScope ls(h, T_OTHER);
-    hipLaunchKernelGGL(swk::k_mt_generate, dim3(S), dim3(SW_MT_BLOCK), 0, h->stream,
+    hipLaunchKernelGGL(swk::k_mt_generate, dim3(S), dim3(SW_MT_BLOCK), 0, gs,
                        (const uint32_t*)(h->mt_win + (size_t)SW_MT_N * h->mt_cur),
                        (const uint32_t*)h->mt_family, (unsigned long long)segdraws,
                        (unsigned long long)total, kind, sl.p);
@@ -3731,6 +3758,9 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
   }
   sl.level = level;
   sl.nb = nb;
+  if (!sl.ready) HIPCHK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(sl.ready, gs));
+  sl.pending = true;
   return 0;
 }
 
@@ -3741,6 +3771,7 @@ int sw_probes_fetch(sw_engine* h, int slot, int8_t* out) {
     return sw_fail(h, "probe slot %d is empty", slot);
   HIPCHK(hipSetDevice(h->device));
   SWCHK(stream_sync(h));
+  HIPCHK(hipStreamSynchronize(h->gen_stream));
   const sw_engine::ProbeSlot& sl = h->slots[slot];
   const size_t bytes = (size_t)sl.nb * h->hier[0].lv[sl.level].n;
   HIPCHK(hipMemcpy(out, sl.p, bytes, hipMemcpyDeviceToHost));
@@ -3816,6 +3847,11 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
   const int n = lv.n;
   SWCHK(ensure_probe_ws(h, nbp));
   SWCHK(ensure_small(h, nbp));
+  if (h->pb_slot >= 0 && h->pb_slot < (int)h->slots.size() && h->slots[h->pb_slot].pending) {
+    // the slot was (or is being) generated on the generation stream
+    HIPCHK(hipStreamWaitEvent(h->stream, h->slots[h->pb_slot].ready, 0));
+    h->slots[h->pb_slot].pending = false;
+  }
   // x0 <- probes
   {
     LaunchScope ls(h, T_OTHER);
@@ -4010,6 +4046,7 @@ int sw_comm_destroy(sw_engine* h) {
 int sw_sync(sw_engine* h) {
   if (!h) return 1;
   HIPCHK(hipSetDevice(h->device));
+  if (h->gen_stream) HIPCHK(hipStreamSynchronize(h->gen_stream));
   return stream_sync(h);
 }
 
@@ -4097,6 +4134,7 @@ int sw_bench_dirac(sw_engine* h, int hid, int level, int nb, int reps, double* m
 
 int sw_set_profiling(sw_engine* h, int on) {
   if (!h) return 1;
+  if (h->gen_stream) HIPCHK(hipStreamSynchronize(h->gen_stream));
   SWCHK(stream_sync(h));
   h->profiling = on != 0;
   return 0;

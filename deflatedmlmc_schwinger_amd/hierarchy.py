@@ -622,6 +622,12 @@ TUNED_SOLVER_CFG_128 = {
     "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count
     "setup": "device",
     "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,
+    # the 4096-row level is solved exactly in even-odd reduced form: dense inverse of its 2048-row Schur
+    # complement (formed on the device, sw_setup_direct_level) on the matrix cores -- four launches per
+    # visit instead of the ~16 of ten Schur steps plus the level below (round 3: 355 -> 223 launches per
+    # batch, one stream 25.4k -> 28.7k probe-samples/s; the 1024-row level stays in the hierarchy for the
+    # setup's coarse correction and for eo_direct = 0)
+    "direct_levels": [1],
 }
 # cfg["eo_smoother"] = True: the post-smoothing steps of level 0 (cycle[0][1] of them) run on the
 # even-odd Schur complement (sw_set_eo_smoother) instead of the full operator.

@@ -83,7 +83,9 @@ class HostProbes:
 
 class DeviceProbes:
     """Probe source of the GPU estimators: the engines generate their probes in HBM at the
-    probes' stream positions (k_mt_generate) and evaluate them; nothing of size n touches the host."""
+    probes' stream positions (k_mt_generate) and evaluate them; nothing of size n touches the host.
+    The probes of the round expected next (`round_stride` probes further down the stream, set by the
+    loop) are drawn on the engines' generation streams while the current round is being solved."""
 
     def __init__(self, mg_solver, params, method, level, kind="z2"):
         self.mg_solver = mg_solver
@@ -91,15 +93,21 @@ class DeviceProbes:
         self.method = method
         self.level = level
         self.kind = kind
+        self.round_stride = 0          # distance (in probes) to this rank's slice of the next round
+        self._ready = None
 
     def begin(self, entry_stream):
         window = entry_stream.window()
         for eng in _engines(self.mg_solver):
             eng.stream_set(window)
+        self._ready = None
 
     def __call__(self, first_probe, count):
-        return probe_batch_generated(self.mg_solver, self.params, self.method, self.level,
-                                     first_probe, count, self.kind)
+        nxt = (first_probe + self.round_stride, count) if self.round_stride > 0 else None
+        e, f, c, self._ready = probe_batch_generated(self.mg_solver, self.params, self.method, self.level,
+                                                     first_probe, count, self.kind, prefetch=nxt,
+                                                     ready=self._ready)
+        return e, f, c
 
 
 def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_index=5,
@@ -128,6 +136,9 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
         round_size = min(batch * comm.world, max_nr_ests - ests.size)
         first_new = ests.size
         lo, hi = comm.my_slice(round_size)
+        if hasattr(source, "round_stride"):
+            # the next round (if the loop goes on and is a full one) starts round_size probes further on
+            source.round_stride = round_size if ests.size + 2 * round_size <= max_nr_ests else 0
         if hi > lo:
             e, f, c = source(first_new + lo, hi - lo)
         else:

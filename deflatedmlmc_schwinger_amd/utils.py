@@ -277,11 +277,18 @@ def _probe_mode(mg_solver, method, level):
     raise Exception("unknown method")
 
 
-def probe_batch_generated(mg_solver, params, method, level, first_probe, count, kind="z2"):
+def probe_batch_generated(mg_solver, params, method, level, first_probe, count, kind="z2",
+                          prefetch=None, ready=None):
     """Like probe_batch, for the probes [first_probe, first_probe + count) of the stream the
     engines were handed with Engine.stream_set: each engine GENERATES its contiguous share in
     HBM (k_mt_generate, bit-exact with np.random.randint, utils.py:213-216,255-258) and
-    evaluates it; only the 16-byte estimates come back."""
+    evaluates it; only the 16-byte estimates come back.
+
+    Generation is asynchronous on the engines' generation streams.  `prefetch` = (first_probe, count)
+    of the batch expected NEXT: its probes are queued into the engines' other slot before this batch is
+    solved, so they are drawn while the solve runs; `ready` = the (first_probe, count, slot) a previous
+    call prefetched (skips this batch's own generation when it matches).  Returns
+    (ests, iters_fine, iters_coarse, prefetched) with prefetched = (first, count, slot) or None."""
     engs = _engines(mg_solver)
     if not engs:
         raise EngineError("no GPU engine attached (run MG.setup first)")
@@ -289,22 +296,43 @@ def probe_batch_generated(mg_solver, params, method, level, first_probe, count, 
     n = mg_solver.ml.levels[level].A.shape[0]
     maxiter = n if n < 1000 else 1000
     mode = _probe_mode(mg_solver, method, level)
+    ne = len(engs) if count >= 2 * 64 else 1
 
-    def run(eng, lo, cnt):
-        eng.probes_generate(0, level, cnt, (first_probe + lo) * n, kind)
-        eng.probes_select(0)
+    def shares(cnt):
+        return [(k * cnt) // ne for k in range(ne + 1)]
+
+    slot = 0
+    have = ready is not None and ready[0] == first_probe and ready[1] == count
+    if have:
+        slot = ready[2]
+    bounds = shares(count)
+    if not have:
+        for k in range(ne):
+            if bounds[k + 1] > bounds[k]:
+                engs[k].probes_generate(slot, level, bounds[k + 1] - bounds[k],
+                                        (first_probe + bounds[k]) * n, kind)
+    prefetched = None
+    if prefetch is not None and prefetch[1] > 0 and (ne == (len(engs) if prefetch[1] >= 2 * 64 else 1)):
+        nslot = 1 - slot
+        nb2 = shares(prefetch[1])
+        for k in range(ne):
+            if nb2[k + 1] > nb2[k]:
+                engs[k].probes_generate(nslot, level, nb2[k + 1] - nb2[k], (prefetch[0] + nb2[k]) * n, kind)
+        prefetched = (prefetch[0], prefetch[1], nslot)
+
+    def run(eng):
+        eng.probes_select(slot)
         eng.hutch_run(mode, level, tol, maxiter)
         return eng.hutch_fetch()
 
-    if len(engs) == 1 or count < 2 * 64:
-        return run(engs[0], 0, count)
-    from concurrent.futures import ThreadPoolExecutor
-    bounds = [(k * count) // len(engs) for k in range(len(engs) + 1)]
-    with ThreadPoolExecutor(max_workers=len(engs)) as pool:
-        futs = [pool.submit(run, eng, bounds[k], bounds[k + 1] - bounds[k])
-                for k, eng in enumerate(engs) if bounds[k + 1] > bounds[k]]
-        res = [f.result() for f in futs]
-    return tuple(np.concatenate([r[k] for r in res]) for k in range(3))
+    active = [engs[k] for k in range(ne) if bounds[k + 1] > bounds[k]]
+    if len(active) == 1:
+        res = [run(active[0])]
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(active)) as pool:
+            res = list(pool.map(run, active))
+    return tuple(np.concatenate([r[k] for r in res]) for k in range(3)) + (prefetched,)
 
 
 def one_defl_Hutch_step(Af, Ac, mg_solver, params, method, nr_deflat_vctrs, Vx, Ux, i=0,

@@ -240,7 +240,9 @@ int sw_probes_select(sw_engine* h, int slot);
  * stream position that becomes position 0 (sw_mt_window() below makes them from a seed or from a
  * NumPy state); sw_probes_generate() fills `slot` with the nb probes whose first entry is draw
  * number `pos` of that stream (one 32-bit draw per entry, bit-exact with NumPy), jumping there
- * with GF(2) jump polynomials -- cost independent of `pos`.  Asynchronous on the engine stream. */
+ * with GF(2) jump polynomials -- cost independent of `pos`.  Asynchronous on a generation stream of the
+ * engine's own: the call returns when the work is queued, the sw_hutch_run that consumes the slot waits
+ * for it on the device -- so the probes of batch k + 1 (another slot) are drawn while batch k is solved. */
 #define SW_PROBES_Z2 1   /* entry = 2*(draw & 1) - 1              (the reference's probes)          */
 #define SW_PROBES_Z4 2   /* draw & 3 -> 1, i, -1, -i as 1,2,-1,-2  (build-only, BASELINE config 1)  */
 int sw_probes_stream_set(sw_engine* h, const uint32_t* window);

@@ -259,6 +259,7 @@ def test_device_arnoldi_gives_a_smoother_polynomial_as_good_as_the_hosts():
     (ii) a polynomial of the device's weights damps a random residual as well as the host-fitted one
     (within a factor 2), for the level operator and for the even-odd Schur complement."""
     params = gateway.set_params('schwinger16')
+    params['function_tol'] = 1e-12
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
     tp = utils.trace_params_from_params(params, "hutchinson")
     tp['solver_cfg'] = dict(hierarchy.DEFAULT_SOLVER_CFG)

@@ -40,8 +40,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nb", type=int, default=256, help="probes per engine stream per step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "3")),
-                    help="concurrent probe batches (engine handles / HIP streams) per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "1")),
+                    help="concurrent probe batches (engine handles / HIP streams) per GPU; one since round "
+                         "3: with the block level solved directly a single batch keeps the GPU busy and "
+                         "its smoother's working set (201 MB) inside the 256 MB Infinity Cache, which three "
+                         "concurrent batches thrash (29.8k / 27.8k / 27.5k probe-samples/s for 1 / 2 / 3)")
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
                     help="JSON solver-hierarchy override")
@@ -60,6 +63,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-line", action="store_true",
                     help="skip the secondary measurement with the single-precision preconditioner")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact driver-run records of the other BASELINE configurations "
+                         "(config 2 as written, config 3's MLMC difference, config 5's 1024^2 lattice, the "
+                         "strict parity mode, the drop-in G102 / G202 flows)")
     ap.add_argument("--no-large-stencil", action="store_true",
                     help="skip the synthetic 1024^2 stencil roofline point")
     ap.add_argument("--engine-opts", type=str, default=os.environ.get("SW_ENGINE_OPTS", ""),
@@ -117,6 +124,179 @@ def main():
     os.close(real_stdout)
 
 
+def build_problem(workload, args, device_index, engines):
+    """Operands, hierarchies and deflation vectors of one workload (untimed setup).
+    Returns (mg, A, trace_params, tr1, unknowns, setup_seconds)."""
+    import contextlib
+    import io
+    from deflatedmlmc_schwinger_amd import gateway, matrix, utils
+    from deflatedmlmc_schwinger_amd import hierarchy as swhier
+    from deflatedmlmc_schwinger_amd.multigrid import MG
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = args.tol
+    params['device'] = device_index
+    params['engines'] = engines
+    if args.cfg and workload == args.workload:
+        params['solver_cfg'] = json.loads(args.cfg)
+    elif workload in ("hutchinson", "mlmc"):
+        params['solver_cfg'] = dict(swhier.TUNED_SOLVER_CFG_128)
+    t_setup = time.time()
+    if workload == "synthetic":
+        # BASELINE config 5: sigma = 0.204 <-> mean plaquette ~0.92, m = -0.05
+        Ls = args.lattice
+        U1s, U2s = matrix.synthetic_links(Ls, 0.204, 2024)
+        # hierarchy.synthetic_solver_cfg: 8x8 site aggregates once, then 2x2 down to 16 x 16 sites, every
+        # level smoothed even-odd, a 2-step K-cycle on level 1 (profiles/r02_synthetic_lattices.txt,
+        # 1024^2: 408 probe-samples/s, 9 iterations; Schur steps on the lattice level: 10 -- 512^2: 1377
+        # probe-samples/s against 1331 with 14, 1024^2: 408 against 386, one more outer iteration)
+        scfg = swhier.synthetic_solver_cfg(Ls, int(os.environ.get("SW_SYNTH_NU0", "10")),
+                                           os.environ.get("SW_SYNTH_SETUP", "device"))
+        if args.cfg and workload == args.workload:
+            scfg = json.loads(args.cfg)
+        mg = MG((Ls, -0.05, U1s, U2s))
+        with contextlib.redirect_stdout(io.StringIO()):
+            mg.setup_solver_only(scfg, device=device_index, engines=engines)
+        return mg, None, None, 0.0, 2 * Ls * Ls, time.time() - t_setup
+    if workload == "config2":
+        # BASELINE config 2 as written: plain Hutchinson, 2-level MG 32768 -> 8192 from the
+        # reference's own aggregation, dense coarse inverse; no solver hierarchy, no deflation
+        params['max_nr_levels'] = 2
+        params['nr_deflat_vctrs'] = 0
+        params['use_solver_hierarchy'] = False
+        params['ref_smoother'] = 'richardson'
+        params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "48"))
+        params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "16"))
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc" if workload == "mlmc" else "hutchinson")
+    mg = MG(A)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+                 acc_eigvs=tp['accuracy_mg_eigvs'], sys_type=tp['problem_name'], params=tp)
+        Ux, tr1 = utils.deflation_pre_computations(A, tp['nr_deflat_vctrs'],
+                                                   tp['defl_eigvs_tol_Hutch'], "hutchinson",
+                                                   mg.timer, tp, mg)
+    return mg, A, tp, tr1, A.shape[0], time.time() - t_setup
+
+
+KERNEL_CLASSES = (("k_stencil<0>", 8), ("k_stencil<1>", 9), ("k_stencil<2>", 10),
+                  ("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
+                  ("k_bsr_mfma(level-2 operator)", 14), ("k_schur_step", 15),
+                  ("k_schur_step<0/1> (S x, b' - S x)", 16))
+MFMA_CLASSES = (("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
+                ("k_bsr_mfma(level-2 operator)", 14))
+
+
+def kernel_rooflines(eng, levels, V, nbp, pmc=None, skip=(), three_products=True):
+    """Per-kernel-class roofline records from the engine's HIP-event buckets of an instrumented batch
+    (profiling on): achieved = algorithmic bytes (or issued flops) per launch / average launch time
+    (DESIGN.md section 5), sorted by the class's share of the batch."""
+    kstats = {name: eng.kernel_stats(cls) for name, cls in KERNEL_CLASSES if name not in skip}
+    kwork = {name: eng.kernel_work(cls) for name, cls in MFMA_CLASSES}
+    nc = levels[-1]
+    algo = {
+        "k_stencil<0>": ("hbm", V * (64.0 * nbp + 32.0)),              # SURVEY 8d
+        "k_stencil<1>": ("hbm", V * (96.0 * nbp + 32.0)),              # + read of B
+        "k_stencil<2>": ("hbm", V * (96.0 * nbp + 32.0)),              # fused smoother step
+        # even-odd smoother step / hop: three HALF-vector passes (x_e, b'_e in, x_e out) + links
+        "k_schur_step": ("hbm", 0.5 * V * (96.0 * nbp + 64.0)),
+        # operator of the even-odd reduced system (outer Krylov solver on half vectors): two
+        # half-vector passes (the few residual launches, three, are counted at the same figure)
+        "k_schur_step<0/1> (S x, b' - S x)": ("hbm", 0.5 * V * (64.0 * nbp + 64.0)),
+        "k_bsr_mfma(dense coarsest)": ("mfma", 8.0 * nc * nc * nbp),
+        "k_bsr_mfma(level-1 operator)": ("mfma", 8.0 * levels[1] * 80.0 * nbp if len(levels) > 2 else 0.0),
+        # (with more than one such level the class averages over them; the 128^2 hierarchies have one)
+        "k_bsr_mfma(level-2 operator)": ("mfma", 8.0 * levels[2] * 80.0 * nbp if len(levels) > 3 else 0.0),
+    }
+    peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (MFMA_F64_PEAK_TFLOPS, "TFLOP/s", 1e12)}
+    pmc = pmc or {}
+    out = []
+    for name, (ms_tot, cnt) in kstats.items():
+        if cnt == 0:
+            continue
+        bound, work = algo[name]
+        if name in kwork and kwork[name] > 0.0:
+            # MFMA classes: the complex multiply-adds the launches performed, at 8 real flops each (full
+            # operator, even-odd Schur steps, dense inverses have different shapes), counted by the
+            # engine.  (The three-product kernel issues 6 real flops per complex multiply-add: `achieved`
+            # is the ALGORITHMIC rate, and may approach 4/3 of what the matrix cores execute.)
+            work = kwork[name] / cnt
+        peak, unit, scale = peaks[bound]
+        avg_ms = ms_tot / cnt
+        ach = work / (avg_ms * 1e-3) / scale
+        rec = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+               "frac": ach / peak, "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
+               "work_per_launch": work, "avg_launch_ms": avg_ms, "launches_in_step": cnt, "step_ms": ms_tot}
+        if rec["traffic"] is not None:
+            rec["traffic_source"] = "profiles/kernel_pmc.json (rocprofv3 --pmc passes of this workload, builder-run)"
+        if bound == "mfma" and three_products:
+            # k_bsr_mfma3 executes 6 real flops per complex multiply-add, `achieved` counts 8
+            rec["executed_frac_of_peak"] = rec["frac"] * 0.75
+        out.append(rec)
+    out.sort(key=lambda r: -r["step_ms"])
+    return out
+
+
+def secondary(label, mg, run_mode, nb, n, tol, steps, warmup, engine_opts=None):
+    """A compact driver-run record of another BASELINE configuration on ONE engine / one stream:
+    `steps` timed batches (probes generated on the device inside the timed region, next batch
+    prefetched), then one instrumented batch for the dominant kernel and its roofline fraction."""
+    import torch
+    from deflatedmlmc_schwinger_amd.engine import ProbeStream
+    eng = mg.engine
+    for k, v in (engine_opts or {}).items():
+        eng.set_option(k, v)
+    eng.stream_set(ProbeStream(123456).window())
+    its = []
+
+    def one(s, prefetch):
+        slot = s & 1
+        if s == 0 or not one.ready:
+            eng.probes_generate(slot, 0, nb, s * nb * n)
+        one.ready = False
+        if prefetch:
+            eng.probes_generate(1 - slot, 0, nb, (s + 1) * nb * n)
+            one.ready = True
+        eng.probes_select(slot)
+        eng.hutch_run(run_mode, 0, tol, 1000)
+        e, itf, _ = eng.hutch_fetch()
+        its.append(int(itf.max()))
+        return e
+    one.ready = False
+    for s in range(warmup):
+        one(s, False)
+    one.ready = False
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        one(s, s < warmup + steps - 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(True)
+    eng.timers_reset()
+    one.ready = False
+    one(warmup + steps, False)
+    levels = mg.solver_info["levels"] if mg.solver_info else [lev.A.shape[0] for lev in mg.ml.levels]
+    L = mg.lattice[0]
+    nbp = ((nb + 63) // 64) * 64
+    roofs = kernel_rooflines(eng, levels, L * L, nbp,
+                             skip=("k_bsr_mfma(level-1 operator)", "k_bsr_mfma(level-2 operator)")
+                             if len(levels) > 3 and mg.solver_info else ())
+    buckets = eng.timers()
+    launches = eng.launch_count()
+    eng.set_profiling(False)
+    for k in (engine_opts or {}):
+        eng.set_option(k, {"stop_factor": 1.0}.get(k, 1.0))
+    dom = roofs[0] if roofs else None
+    return {"workload": label, "value": steps * nb / dt, "unit": "probe-samples/s", "steps": steps,
+            "probes_per_step": nb, "ms_per_step": 1e3 * dt / steps,
+            "outer_iterations_max": max(its[warmup:warmup + steps]),
+            "levels": levels, "kernel_launches_per_batch": launches,
+            "step_breakdown_ms": buckets,
+            "dominant_kernel": None if dom is None else
+            {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                 "launches_in_step", "step_ms")}}
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -141,61 +321,10 @@ def run(args):
     from deflatedmlmc_schwinger_amd.multigrid import MG, REF_HID
 
     # ---- setup (untimed): operands, hierarchies, deflation vectors --------------------
-    import contextlib
-    import io
-    params = gateway.set_params('schwinger128')
-    params['function_tol'] = args.tol
-    params['device'] = device_index
-    params['engines'] = max(1, args.streams)
     from deflatedmlmc_schwinger_amd import hierarchy as swhier
-    if args.cfg:
-        params['solver_cfg'] = json.loads(args.cfg)
-    elif args.workload in ("hutchinson", "mlmc"):
-        params['solver_cfg'] = dict(swhier.TUNED_SOLVER_CFG_128)
     synthetic = args.workload == "synthetic"
     run_mode = MODE_MLMC_SKIP if args.workload == "mlmc" else MODE_HUTCHINSON
-    t_setup = time.time()
-    if synthetic:
-        # BASELINE config 5: sigma = 0.204 <-> mean plaquette ~0.92, m = -0.05
-        Ls = args.lattice
-        U1s, U2s = matrix.synthetic_links(Ls, 0.204, 2024)
-        # hierarchy.synthetic_solver_cfg: 8x8 site aggregates once, then 2x2 down to 16 x 16 sites, every
-        # level smoothed even-odd, a 2-step K-cycle on level 1 (profiles/r02_synthetic_lattices.txt,
-        # 1024^2: 408 probe-samples/s, 9 iterations; Schur steps on the lattice level: 10 -- 512^2: 1377
-        # probe-samples/s against 1331 with 14, 1024^2: 408 against 386, one more outer iteration)
-        scfg = swhier.synthetic_solver_cfg(Ls, int(os.environ.get("SW_SYNTH_NU0", "10")),
-                                           os.environ.get("SW_SYNTH_SETUP", "device"))
-        if args.cfg:
-            scfg = json.loads(args.cfg)
-        mg = MG((Ls, -0.05, U1s, U2s))
-        with contextlib.redirect_stdout(io.StringIO()):
-            mg.setup_solver_only(scfg, device=device_index, engines=max(1, args.streams))
-        tr1 = 0.0
-        tp = None
-        A = None
-        n_unknowns = 2 * Ls * Ls
-    else:
-        config2 = args.workload == "config2"
-        if config2:
-            # BASELINE config 2 as written: plain Hutchinson, 2-level MG 32768 -> 8192 from the
-            # reference's own aggregation, dense coarse inverse; no solver hierarchy, no deflation
-            params['max_nr_levels'] = 2
-            params['nr_deflat_vctrs'] = 0
-            params['use_solver_hierarchy'] = False
-            params['ref_smoother'] = 'richardson'
-            params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "48"))
-            params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "16"))
-        A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
-        tp = utils.trace_params_from_params(params, "mlmc" if args.workload == "mlmc" else "hutchinson")
-        mg = MG(A)
-        with contextlib.redirect_stdout(io.StringIO()):
-            mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
-                     acc_eigvs=tp['accuracy_mg_eigvs'], sys_type=tp['problem_name'], params=tp)
-            Ux, tr1 = utils.deflation_pre_computations(A, tp['nr_deflat_vctrs'],
-                                                       tp['defl_eigvs_tol_Hutch'], "hutchinson",
-                                                       mg.timer, tp, mg)
-        n_unknowns = A.shape[0]
-    t_setup = time.time() - t_setup
+    mg, A, tp, tr1, n_unknowns, t_setup = build_problem(args.workload, args, device_index, max(1, args.streams))
     eng = mg.engine
     n = n_unknowns
     L = mg.lattice[0]
@@ -345,14 +474,19 @@ def run(args):
     eng.set_profiling(True)
     eng.timers_reset()
     run_one(0, args.warmup + args.steps)      # one stream alone: clean per-kernel durations
-    kstats = {name: eng.kernel_stats(cls) for name, cls in
-              (("k_stencil<0>", 8), ("k_stencil<1>", 9), ("k_stencil<2>", 10),
-               ("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
-               ("k_bsr_mfma(level-2 operator)", 14), ("k_schur_step", 15),
-               ("k_schur_step<0/1> (S x, b' - S x)", 16))}
-    kwork = {name: eng.kernel_work(cls) for name, cls in
-             (("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
-              ("k_bsr_mfma(level-2 operator)", 14))}
+    levels = mg.solver_info["levels"] if mg.solver_info else [lev.A.shape[0] for lev in mg.ml.levels]
+    pmc_all = {}
+    try:
+        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "kernel_pmc.json")))
+    except Exception:
+        pmc_all = {}
+    if synthetic:
+        pmc_all = {}
+    elif args.workload != "hutchinson":
+        pmc_all = {k: v for k, v in pmc_all.items() if k.startswith(("k_stencil", "k_schur"))}
+    kroofs = kernel_rooflines(eng, levels, V, nbp, pmc_all,
+                              skip=("k_bsr_mfma(level-1 operator)", "k_bsr_mfma(level-2 operator)")
+                              if synthetic else (), three_products="mfma_3m=0" not in args.engine_opts)
     buckets = eng.timers()
     launches = eng.launch_count()
     eng.set_profiling(False)
@@ -361,66 +495,11 @@ def run(args):
 
     if rank == 0:
         mean, std = swdist.mean_and_population_std(total)
-        if mg.solver_info:
-            levels = mg.solver_info["levels"]
-        else:
-            levels = [lev.A.shape[0] for lev in mg.ml.levels]
-        nc = levels[-1]
-        # algorithmic bytes / flops per launch
-        algo = {
-            "k_stencil<0>": ("hbm", V * (64.0 * nbp + 32.0)),
-            "k_stencil<1>": ("hbm", V * (96.0 * nbp + 32.0)),              # + read of B
-            "k_stencil<2>": ("hbm", V * (96.0 * nbp + 32.0)),              # fused smoother step
-            # even-odd smoother step / hop: three HALF-vector passes (x_e, b'_e in, x_e out) + links
-            "k_schur_step": ("hbm", 0.5 * V * (96.0 * nbp + 64.0)),
-            # operator of the even-odd reduced system (outer Krylov solver on half vectors): two
-            # half-vector passes (the few residual launches, three, are counted at the same figure)
-            "k_schur_step<0/1> (S x, b' - S x)": ("hbm", 0.5 * V * (64.0 * nbp + 64.0)),
-            "k_bsr_mfma(dense coarsest)": ("mfma", 8.0 * nc * nc * nbp),
-            "k_bsr_mfma(level-1 operator)": ("mfma", 8.0 * levels[1] * 80.0 * nbp
-                                             if len(levels) > 2 else 0.0),
-            # (with more than one such level the class averages over them; the 128^2 hierarchies have one)
-            "k_bsr_mfma(level-2 operator)": ("mfma", 8.0 * levels[2] * 80.0 * nbp
-                                             if len(levels) > 3 else 0.0),
-        }
-        peaks = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e9), "mfma": (MFMA_F64_PEAK_TFLOPS, "TFLOP/s", 1e12)}
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "kernel_pmc.json")
-        if synthetic:
-            # several coarse levels share the MFMA operator kernel and the PMC figures were taken
-            # on schwinger128: report the stencil and the dense kernel only, without traffic
-            kstats.pop("k_bsr_mfma(level-1 operator)", None)
-            kstats.pop("k_bsr_mfma(level-2 operator)", None)
-        elif os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))
-            except Exception:
-                pmc = {}
-            if args.workload != "hutchinson":
-                # the MFMA kernels' PMC passes were taken on the default workload's operators
-                pmc = {k: v for k, v in pmc.items() if k.startswith("k_stencil")}
-        rooflines = []
-        for name, (ms_tot, cnt) in kstats.items():
-            if cnt == 0:
-                continue
-            bound, work = algo[name]
-            if name in kwork and kwork[name] > 0.0:
-                # MFMA classes: the flops the launches actually issued (full operator, even-odd
-                # Schur steps and their hops have different shapes), counted by the engine
-                work = kwork[name] / cnt
-            peak, unit, scale = peaks[bound]
-            avg_ms = ms_tot / cnt
-            ach = work / (avg_ms * 1e-3) / scale
-            rooflines.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak,
-                              "unit": unit, "frac": ach / peak,
-                              "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
-                              "work_per_launch": work, "avg_launch_ms": avg_ms,
-                              "launches_in_step": cnt, "step_ms": ms_tot})
-        rooflines.sort(key=lambda r: -r["step_ms"])
+        rooflines = kroofs
         dominant = rooflines[0] if rooflines else None
         stencil = max((r for r in rooflines if r["kernel"].startswith(("k_stencil", "k_schur"))),
                       key=lambda r: r["step_ms"], default=None)
-        bytes0 = algo["k_stencil<0>"][1]
+        bytes0 = V * (64.0 * nbp + 32.0)      # Y = A X, one launch
         out = {
             "metric": {"hutchinson": "hutchinson_probe_samples_per_sec_schwinger128",
                        "config2": "hutchinson_probe_samples_per_sec_schwinger128",
@@ -486,11 +565,110 @@ def run(args):
             out["stencil_roofline_1024"] = large_stencil_point()
         if world == 1 and not args.no_cpu_baseline and args.workload == "hutchinson":  # 128^2 only
             out["cpu_baseline"] = cpu_baseline(A, tp, mg, args.cpu_probes, args.cpu_workers)
+        if world == 1 and args.workload == "hutchinson" and not args.no_other_configs:
+            out["other_configs"] = other_configs(args, mg, n, device_index)
         line_out = json.dumps(out)
     if td.is_initialized():
         comm.barrier()
         td.destroy_process_group()
     return line_out
+
+
+def other_configs(args, mg, n, device_index):
+    """Compact records of the BASELINE configurations the headline is not quoted on, measured in the SAME
+    driver-run process (one engine, one stream each): so that they are driver-observed numbers,
+    not builder files.  Each carries its throughput, iteration count, launch count and dominant kernel."""
+    import contextlib
+    import io
+    import tempfile
+    from deflatedmlmc_schwinger_amd.engine import MODE_HUTCHINSON, MODE_MLMC_SKIP
+    out = {}
+    t_all = time.time()
+
+    def guarded(key, fn):
+        t0 = time.time()
+        try:
+            out[key] = fn()
+        except Exception as exc:            # a secondary record must never cost the headline line
+            out[key] = {"error": repr(exc)}
+        if isinstance(out[key], dict):
+            out[key]["wall_s"] = round(time.time() - t0, 2)
+
+    # the headline workload again in the strict per-probe parity mode (every true residual below 0.1 tol;
+    # tests/test_gpu_golden.py: all 256 estimates within 1e-10 relative of the LU oracle)
+    guarded("parity_mode_stop_factor_0.1", lambda: secondary(
+        "headline workload with engine option stop_factor = 0.1 (strict 1e-10 per-probe parity)", mg,
+        MODE_HUTCHINSON, args.nb, n, args.tol, 4, 1, {"stop_factor": 0.1}))
+    # config 3: MLMC level-0 difference probes (level skipping, reference hierarchy 32768/8192/2048/512)
+    guarded("config3_mlmc_level0_difference", lambda: secondary(
+        "schwinger128 MLMC level-0 difference probes A0^-1 - P0 P1 A2^-1 R1 R0 (reference hierarchy "
+        "32768/8192/2048/512, level skipping)", mg, MODE_MLMC_SKIP, args.nb, n, args.tol, 4, 1))
+
+    def config2():
+        mg2, A2, tp2, _, n2, ts = build_problem("config2", args, device_index, 1)
+        try:
+            r = secondary("BASELINE config 2 as written: plain Hutchinson (k=0), 2-level multigrid 32768 -> "
+                          "8192 (reference aggregation), dense 8192^2 coarse inverse on fp64 MFMA",
+                          mg2, MODE_HUTCHINSON, args.nb, n2, args.tol, 2, 1)
+            r["setup_s"] = ts
+            return r
+        finally:
+            for e_ in mg2.engines:
+                e_.close()
+    guarded("config2_as_written", config2)
+
+    def config5():
+        a5 = argparse.Namespace(**vars(args))
+        a5.lattice = 1024
+        a5.cfg = ""
+        mg5, _, _, _, n5, ts = build_problem("synthetic", a5, device_index, 1)
+        try:
+            r = secondary("BASELINE config 5's lattice: synthetic 1024^2 random U(1) gauge field (sigma 0.204, "
+                          "m -0.05), 64 plain Hutchinson probes per batch, five-level hierarchy built on the GPU",
+                          mg5, MODE_HUTCHINSON, 64, n5, args.tol, 2, 1)
+            r["setup_s"] = ts
+            r["setup_log"] = (mg5.solver_info or {}).get("setup_log")
+            return r
+        finally:
+            for e_ in mg5.engines:
+                e_.close()
+    guarded("config5_synthetic_1024", config5)
+
+    # the drop-in flows as main.py:20-22 runs them (gateway.G202 / G102: setup, deflation vectors, rough
+    # trace, probe loops with the sequential stopping rule), wall clock and probe-loop throughput; the ARPACK
+    # products are shared between the two through the on-disk cache (SW_CACHE_DIR), the first run fills it
+    def flow(name):
+        from deflatedmlmc_schwinger_amd import gateway
+        rep = os.path.join(cache, name + ".jsonl")
+        os.environ["SW_REPORT_PATH"] = rep
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = getattr(gateway, name)()
+        dt = time.time() - t0
+        rec = json.loads(open(rep).read().splitlines()[-1])
+        keep = {k: rec[k] for k in ("trace", "elapsed_s", "nr_ests", "std_dev", "probes_solved", "probe_loop_s",
+                                    "probe_loop_solved_per_s", "probe_loop_used_per_s", "levels") if k in rec}
+        keep["wall_s_with_setup"] = dt
+        keep["exact_trace_gateway_py_104"] = [gateway.EXACT_TRACE_SCHWINGER128.real,
+                                              gateway.EXACT_TRACE_SCHWINGER128.imag]
+        del res
+        return keep
+    cache = tempfile.mkdtemp(prefix="sw_bench_cache_")
+    old_env = {k: os.environ.get(k) for k in ("SW_CACHE_DIR", "SW_REPORT_PATH")}
+    os.environ["SW_CACHE_DIR"] = cache
+    try:
+        guarded("dropin_G202_mlmc", lambda: flow("G202"))
+        guarded("dropin_G102_hutchinson", lambda: flow("G102"))
+    finally:
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        import shutil
+        shutil.rmtree(cache, ignore_errors=True)
+    out["total_wall_s"] = round(time.time() - t_all, 1)
+    return out
 
 
 def large_stencil_point(L=1024, nb=64, reps=20):

@@ -182,6 +182,8 @@ struct sw_engine {
   int bench_what = 0;      // what sw_bench_dirac times: 0 operator, 1 restrict, 2 prolong, 3 coarsest inverse
   int bench_mode = 0;      // operator mode sw_bench_dirac times (0: Y=AX, 1: residual, 2: smoother step)
   bool mfma_ops = true;   // MFMA block-row kernel also for block-structured level operators
+  bool mfma_3m = true;    // three real matrix products per complex one (k_bsr_mfma3) instead of four
+  int mfma3_tiles = 0;    // tiles of 16 probes per wave in k_bsr_mfma3 (0: by the operator's size)
   int mfma_tiles = 4;
   int f32_tiles = 0;          // tiles of 16 probes per wave in k_bsr_mfma_f32 (0: automatic)
   int f32_stages = 4, f32_dense_stages = 8;
@@ -496,6 +498,41 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   LaunchScope ls(h, cls);
   // 16 rows x 4 columns x nbp probes x 8 flops per complex multiply-add, per (tile, k-step)
   if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
+  if (h->mfma_3m) {
+    // three real products per complex one (k_bsr_mfma3): tiles of 16 probes per wave
+    // Measured (gpurun_out r03d): one tile of 16 probes per wave wins wherever it was compared -- the
+    // dense 2048^2 Schur inverse 138 us against 234 (two tiles) and 391 (four): more tiles mean more
+    // stage registers (204 + 106 at two tiles and eight stages: one wave per SIMD), and the kernel lives on
+    // two or three co-resident waves hiding each other's L1 round trips.  Larger level operators (lattices
+    // beyond 128^2) keep two tiles per wave when they have the waves to spare.
+    int NT3 = 1;
+    if (cat != T_COARSEST && (long long)RT * (nbp / 32) >= 16384) NT3 = 2;
+    if (h->mfma3_tiles == 1 || h->mfma3_tiles == 2 || h->mfma3_tiles == 4) NT3 = h->mfma3_tiles;
+    while (NT3 > 1 && nbp % (16 * NT3)) NT3 >>= 1;
+    const int NC3 = nbp / (16 * NT3);
+    const dim3 grid3(RBn * NC3);
+    const bool ntio3 = h->bsr_nt && cat != T_COARSEST;
+    const int xr = (op.bsr_diag_last && h->bsr_xreg) ? 1 : 0;
+    const int bm3 = (bmap == 0) ? 0 : bmap;
+#define B3_LAUNCH(MD, NTT, NTB, SG)                                                              \
+  hipLaunchKernelGGL((swk::k_bsr_mfma3<MD, NTT, NTB, SG>), grid3, dim3(SW_BLOCK), 0, h->stream,   \
+                     (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, B, Y, nbp, \
+                     w, bm3, msub, (const int*)op.bsr_tmap, xr)
+#define B3_NT(MD, NTB, SG)                        \
+  do {                                            \
+    if (NT3 == 4) B3_LAUNCH(MD, 4, NTB, SG);      \
+    else if (NT3 == 2) B3_LAUNCH(MD, 2, NTB, SG); \
+    else B3_LAUNCH(MD, 1, NTB, SG);               \
+  } while (0)
+    if (!ntio3 && mode == 0 && want >= 8) B3_NT(0, false, 8);
+    else if (mode == 0) { if (ntio3) B3_NT(0, true, 4); else B3_NT(0, false, 4); }
+    else if (mode == 1) { if (ntio3) B3_NT(1, true, 4); else B3_NT(1, false, 4); }
+    else { if (ntio3) B3_NT(3, true, 4); else B3_NT(3, false, 4); }
+#undef B3_NT
+#undef B3_LAUNCH
+    KLAUNCH_CHECK();
+    return 0;
+  }
   const double* Xr = (const double*)X;
   const double* Br = (const double*)B;
   double* Yr = (double*)Y;
@@ -3099,6 +3136,16 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "lazy_sync") == 0) {
     h->lazy_sync = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "mfma_3m") == 0) {
+    h->mfma_3m = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "mfma3_tiles") == 0) {
+    const int v = (int)value;
+    if (v != 0 && v != 1 && v != 2 && v != 4) return sw_fail(h, "mfma3_tiles must be 0, 1, 2 or 4");
+    h->mfma3_tiles = v;
     return 0;
   }
   if (std::strcmp(name, "mfma_ops") == 0) {

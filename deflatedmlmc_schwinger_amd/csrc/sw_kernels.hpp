@@ -655,6 +655,134 @@ __global__ __launch_bounds__(SW_BLOCK, SW_BSR_MIN_WAVES(NT, STG)) void k_bsr_mfm
 }
 
 // ------------------------------------------------------------------------------------------
+// The block-row operator with THREE real matrix products per complex one ("3M"):
+//   T1 = Ar Xr,  T2 = Ai Xi,  T3 = (Ar + Ai)(Xr + Xi);   Re Y = T1 - T2,   Im Y = T3 - T1 - T2
+// -- 3 v_mfma_f64_16x16x4 per (k-step, 16 probes) instead of the 4 of k_bsr_mfma (2 per 8 probes): a
+// quarter of the matrix-core time of the dense inverses, which are MFMA-bound.  The sums Ar + Ai and
+// Xr + Xi cost one VALU add per loaded value.  X and Y are used as COMPLEX [n][nbp] arrays: a lane
+// holds one complex probe value of a 4-row k-step (lane l: row l >> 4 of the step, probe l & 15 of the
+// tile: 16 lanes x 16 B = one 256-B segment per row), the accumulators come out as
+// D[(l >> 4) + 4 r][l & 15], so a lane owns whole complex results and the epilogue needs no lane
+// exchange.  Norm-wise the result is as accurate as the four-product form (error bound
+// c eps (|Ar| + |Ai|)(|Xr| + |Xi|)); component-wise Im Y may lose relative accuracy where it cancels,
+// which no consumer here depends on (operator applications are compared norm-wise, 1e-13).
+// A is packed as for k_bsr_mfma (same kcol, same lane order).  One wave = one 16-row tile x NT tiles of
+// 16 probes.  MODE as k_bsr_mfma; xreg: the wave's own X rows from the operand registers of the diagonal
+// block's four k-steps (packed last), in exactly the accumulators' lane layout.
+// ------------------------------------------------------------------------------------------
+#define SW_BSR3_MIN_WAVES(NT_, STG_) (((NT_) <= 2 && (STG_) <= 4) ? 2 : 1)
+
+template <int MODE, int NT, bool NTIO = false, int STG = 4>
+__global__ __launch_bounds__(SW_BLOCK, SW_BSR3_MIN_WAVES(NT, STG)) void k_bsr_mfma3(
+    const cplx* __restrict__ Ap, const int* __restrict__ kcol, int KS, int RT, const cplx* __restrict__ X,
+    const cplx* __restrict__ B, cplx* __restrict__ Y, int nbp, cplx w, int map, int msub,
+    const int* __restrict__ tmap, int xreg) {
+  const int lane = threadIdx.x & 63;
+  // block -> (row block, probe chunk) exactly as k_bsr_mfma (1-D grid of RB x NC blocks)
+  const int RB = (RT + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const int NC = gridDim.x / RB;
+  int bx, cy;
+  if (map == 0 || map == 3 || (RB & 7)) {
+    cy = blockIdx.x / RB;
+    bx = xcd_remap(blockIdx.x - cy * RB, RB);
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, RBx = RB >> 3;
+    if (map == 1 || (RBx % msub)) {
+      cy = j % NC;
+      bx = xcd * RBx + j / NC;
+    } else {
+      const int per = NC * msub;
+      const int sidx = j / per, rem = j - sidx * per;
+      cy = rem / msub;
+      bx = xcd * RBx + sidx * msub + (rem - cy * msub);
+    }
+  }
+  const int rt = __builtin_amdgcn_readfirstlane(bx * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (rt >= RT) return;
+  const int c0 = cy * (16 * NT);                    // first probe of this chunk
+  const cplx* a = Ap + (size_t)rt * KS * 64 + lane;
+  const int* kc = kcol + (size_t)rt * KS;           // wave-uniform -> scalar loads
+  const cplx* b = X + (size_t)(lane >> 4) * nbp + c0 + (lane & 15);
+  sw_double4 t1[NT], t2[NT], t3[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    t1[t] = sw_double4{0.0, 0.0, 0.0, 0.0};
+    t2[t] = t1[t];
+    t3[t] = t1[t];
+  }
+#define SW_B3_LOAD(M_, X_, KSI)                                 \
+  {                                                             \
+    M_ = a[(size_t)(KSI) * 64];                                 \
+    const cplx* bk_ = b + (size_t)kc[(KSI)] * nbp;              \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) X_[t] = bk_[t * 16]; \
+  }
+#define SW_B3_MFMA(M_, X_)                                                                  \
+  {                                                                                         \
+    const double ms_ = M_.x + M_.y;                                                         \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                        \
+      t1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.x, X_[t].x, t1[t], 0, 0, 0);          \
+      t2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(M_.y, X_[t].y, t2[t], 0, 0, 0);          \
+      t3[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ms_, X_[t].x + X_[t].y, t3[t], 0, 0, 0); \
+    }                                                                                       \
+  }
+  cplx mm[STG];
+  cplx xx[STG][NT];
+#pragma unroll
+  for (int s = 0; s < STG; ++s) SW_B3_LOAD(mm[s], xx[s], (s < KS ? s : 0));
+  for (int ks = 0; ks < KS; ks += STG) {
+#pragma unroll
+    for (int s = 0; s < STG; ++s) {
+      if (ks + s < KS) {                                              // KS need not divide by STG
+        const int kn = (ks + s + STG < KS) ? ks + s + STG : ks + s;   // tail: harmless re-load
+        __builtin_amdgcn_sched_barrier(0);
+        SW_B3_MFMA(mm[s], xx[s]);
+        __builtin_amdgcn_sched_barrier(0);
+        SW_B3_LOAD(mm[s], xx[s], kn);
+      }
+    }
+  }
+#undef SW_B3_LOAD
+#undef SW_B3_MFMA
+  const int ot = tmap ? __builtin_amdgcn_readfirstlane(tmap[rt]) : rt;
+  // after the tail re-loads stage s holds the k-step KS - STG + s (KS % STG == 0): with the diagonal block
+  // last and STG == 4 these are the X rows 16 ot + 4 s + (lane >> 4) -- row r of this lane's results
+  const bool own = MODE == 3 && STG == 4 && xreg && (KS % 4 == 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t row = (size_t)ot * 16 + (lane >> 4) + 4 * r;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const size_t off = row * nbp + c0 + t * 16 + (lane & 15);
+      cplx y = cmake(t1[t][r] - t2[t][r], t3[t][r] - t1[t][r] - t2[t][r]);
+      if (MODE == 1 || MODE == 3) {
+        cplx q;
+        if (NTIO) {
+          const double* bp_ = (const double*)&B[off];
+          q = cmake(__builtin_nontemporal_load(bp_), __builtin_nontemporal_load(bp_ + 1));
+        } else {
+          q = B[off];
+        }
+        y = csub(q, y);
+      }
+      if (MODE == 3) {
+        cplx o;
+        if constexpr (STG == 4) o = own ? xx[r][t] : X[off];
+        else o = X[off];
+        cfma(o, w, y);
+        y = o;
+      }
+      if (NTIO) {
+        double* yp_ = (double*)&Y[off];
+        __builtin_nontemporal_store(y.x, yp_);
+        __builtin_nontemporal_store(y.y, yp_ + 1);
+      } else {
+        Y[off] = y;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Single-precision twin of the block-row kernel (f32 preconditioner): v_mfma_f32_16x16x4_f32 runs
 // at twice the fp64 matrix rate on gfx950 (157 vs 78.6 TFLOP/s) and every stream is half as wide.
 // X and Y are complex64 [n][nbp]; a lane holds ONE complex probe value of a 4-row k-step

@@ -616,7 +616,11 @@ DEFAULT_SOLVER_CFG = {
 # iteration has become cheap enough for the optimum to move; profiles/r02_cfg_sweeps.txt).
 TUNED_SOLVER_CFG_128 = {
     "coarsening": [(8, 8), (2, 8)],
-    "cycle": [(0, 9, 0), (0, 10, 0)],
+    # eight Schur steps on the lattice level (round 3, with the 4096-row level solved directly and one
+    # batch at a time per GPU: 7 / 8 / 9 / 10 / 11 steps -> 30.1k / 31.0k / 29.8k / 30.8k / 29.7k
+    # probe-samples/s at 12 / 11 / 11 / 10 / 10 outer iterations, gpurun_out r03c); ten on the block level
+    # where it is smoothed rather than solved (eo_direct = 0)
+    "cycle": [(0, 8, 0), (0, 10, 0)],
     "smoother": "richardson",
     "eo_levels": [0, 1],        # levels smoothed on their even-odd Schur complement (half vectors)
     "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count

@@ -319,3 +319,47 @@ def test_dense_schur_inverse_built_on_the_device_matches_the_host_route():
         mg.engine.close()
     assert _relerr(res["device"][:, E], res["host"][:, E]) < 1e-10
     assert np.abs(np.delete(res["device"], E, axis=1)).max() == 0.0          # odd rows untouched
+
+
+def test_three_product_block_row_kernel_matches_the_four_product_one():
+    """engine option mfma_3m: the block-row operator with three real matrix products per complex one
+    (k_bsr_mfma3: T1 = Ar Xr, T2 = Ai Xi, T3 = (Ar + Ai)(Xr + Xi)) against the four-product kernel and
+    against NumPy -- level operator (modes Y = A X and the smoother step inside a cycle), the dense
+    coarsest inverse, the even-odd subset operators incl. the dense Schur inverse, for one, two and four
+    tiles of 16 probes per wave and a ragged batch."""
+    A, tp, mg = _tuned128(extra={"direct_levels": [1]})
+    eng = mg.engine
+    n1 = mg.solver_info["levels"][1]
+    nc = mg.solver_info["levels"][-1]
+    Lc = 16
+    site = np.arange(Lc * Lc)
+    even = (((site % Lc) + (site // Lc)) & 1) == 0
+    E = np.nonzero(np.repeat(even, 16))[0]
+    for nb in (3, 70):
+        X1 = _rand((nb, n1), 3 + nb)
+        Xc = _rand((nb, nc), 4 + nb)
+        Xe = np.zeros((nb, n1), dtype=complex)
+        Xe[:, E] = _rand((nb, E.size), 5 + nb)
+        B0 = _rand((nb, A.shape[0]), 6 + nb)
+        ref = None
+        try:
+            for m3, tiles in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 4)):
+                eng.set_option("mfma_3m", m3)
+                eng.set_option("mfma3_tiles", tiles)
+                got = (eng.apply_dirac(SOLVER_HID, 1, X1), eng.coarsest(SOLVER_HID, Xc),
+                       eng.apply_eo_operator(SOLVER_HID, 1, 0, Xe), eng.apply_eo_operator(SOLVER_HID, 1, 4, Xe),
+                       eng.apply_eo_operator(SOLVER_HID, 1, 3, Xe), eng.vcycle(SOLVER_HID, 0, B0))
+                if ref is None:
+                    ref = got
+                    continue
+                for a, b, tol in zip(got, ref, (1e-13, 1e-12, 1e-13, 1e-11, 1e-13, 1e-11)):
+                    assert _relerr(a, b) < tol, (nb, m3, tiles, _relerr(a, b))
+        finally:
+            eng.set_option("mfma_3m", 1)
+            eng.set_option("mfma3_tiles", 0)
+    # and against the operator itself, assembled on the host from the engine's block rows
+    kcol, vals = eng.level_bsr(SOLVER_HID, 1)
+    A1 = hierarchy.matrix_from_block_rows(kcol, vals, n1)
+    X1 = _rand((5, n1), 99)
+    assert _relerr(eng.apply_dirac(SOLVER_HID, 1, X1), (A1 @ X1.T).T) < 1e-13
+    eng.close()

@@ -20,8 +20,8 @@ def main(out, extra=""):
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --streams 1 "
-                     "--no-large-stencil --no-cpu-baseline --no-f32-line" + extra)
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 "
+                     "--no-large-stencil --no-cpu-baseline --no-f32-line --no-other-configs" + extra)
         lines.append("%-72s %7s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
         for r in rows[:24]:
             lines.append("%-72s %7d %12.3f %10.2f %6.2f" % (
@@ -70,6 +70,10 @@ def main(out, extra=""):
                     "k_schur_step<cplx, 2>": "k_schur_step",
                     "k_schur_step<cplx >": "k_schur_step",
                     "k_schur_step<cplx, 0>": "k_schur_step<0/1> (S x, b' - S x)",
+                    "k_bsr_mfma3<0, 1, false, 8>": "k_bsr_mfma(dense coarsest)",
+                    "k_bsr_mfma3<0, 2, false, 8>": "k_bsr_mfma(dense coarsest)",
+                    "k_bsr_mfma3<3, 1, true": "k_bsr_mfma(level-1 operator)",
+                    "k_bsr_mfma3<1, 1, true": "k_bsr_mfma(level-1 operator, residual form)",
                     "k_bsr_mfma<0, 4, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<0, 2, false": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma<3, 4, true": "k_bsr_mfma(level-1 operator)",

@@ -195,6 +195,10 @@ struct sw_engine {
   // is only read back from (hint - 2) on, earlier iterations are queued without a host sync
   int sync_hint[SW_MAX_HIER][SW_MAX_LEVELS] = {{0}};
   bool lazy_sync = true;
+  // time-skewed order of the even-odd smoother's steps on the stencil level (schur_steps): -1 automatic
+  // (strips sized for the Infinity Cache where the smoother's three half vectors exceed it), 0 off,
+  // > 0 strip height in lattice rows
+  int eo_skew = -1;
   bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
   bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
@@ -1156,6 +1160,72 @@ static int coarse_correction(sw_engine* h, Hier& H, int l, int nbp) {
   return vcycle(h, H, l + 1, lc.b, lc.x, nbp);
 }
 
+static swk::StencilArgs eo_stencil_args(sw_engine* h, Level& lv, int nbp);
+
+// The nu Schur steps of an even-odd smoothing pass on the stencil level,
+//   x_e <- x_e + w_k (bp - S x_e),  k = 0 .. nu-1,
+// ping-ponging between `cur` (the iterate on entry) and `nxt`; *result = the buffer the last step wrote.
+// On lattices whose three half vectors (both iterates and bp) exceed the 256 MB Infinity Cache every step
+// would stream them from HBM (1024^2, 64 probes: 3.2 GB per step at 4.2 TB/s).  There the steps run in a
+// TIME-SKEWED order instead (option eo_skew): the lattice rows are cut into strips of H rows; strip by
+// strip, all nu steps are applied before the next strip is touched, step k of a strip working on its rows
+// shifted down by 2 k (a Schur step reaches two lattice rows), so that everything step k reads from step
+// k-1 has been written already -- by the strip itself or by its predecessor:
+//   strip 0          step k : rows [2k, H - 2k)            (a shrinking trapezoid: nothing to its left yet)
+//   strip s >= 1     step k : rows [sH - 2k, (s+1)H - 2k)  (parallelograms)
+//   closing wedge    step k : rows [L - 2k, L + 2k)        (periodic lattice: what the torus still lacks)
+// The two ping-pong buffers suffice (rows of step k and of step k-2 that are still needed never overlap).
+// A strip's working set is 3 (H + 4) rows: chosen to fit the cache, only the first and the last touch of a
+// strip reach HBM.  Same arithmetic per site in another order: results are bit-identical.
+static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx* bp, int nbp, cplx** result) {
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int nu = (int)lv.w_eo.size();
+  const int L = lv.L;
+  auto launch = [&](int k, int row0, int nrows, const cplx* src, cplx* dst) -> int {
+    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
+    a.row0 = row0;
+    a.nrows = nrows;
+    const int items = (nrows > 0 ? nrows : L) * (L / 2);
+    const int bpc = (items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+    LaunchScope ls(h, T_SCHUR);
+    hipLaunchKernelGGL(swk::k_schur_step, dim3(bpc * (nbp / 64)), dim3(SW_BLOCK), 0, h->stream, src, bp, dst, a,
+                       bpc);
+    KLAUNCH_CHECK();
+    return 0;
+  };
+  // strip height: 0 = no skewing
+  int H = 0;
+  if (h->eo_skew != 0 && nu >= 2) {
+    const double row_bytes = (double)(L / 2) * 2.0 * sizeof(cplx) * nbp;        // one lattice row of a half vector
+    if (h->eo_skew > 0) H = h->eo_skew;
+    else if (3.0 * row_bytes * L > 208.0e6) {
+      H = 1;
+      while (2 * H <= L / 2 && 3.0 * row_bytes * (2 * H) <= 208.0e6) H *= 2;
+    }
+    if (H > 0 && (L % H != 0 || L / H < 2 || H <= 4 * (nu - 1) || (H & 1))) H = 0;
+  }
+  if (H == 0) {
+    for (int k = 0; k < nu; ++k) {
+      SWCHK(launch(k, 0, 0, cur, nxt));
+      std::swap(cur, nxt);
+    }
+    *result = cur;
+    return 0;
+  }
+  // buf[k & 1] receives step k; step k reads buf[(k + 1) & 1] (step 0: the iterate on entry, in `cur`)
+  cplx* buf[2] = {nxt, cur};
+  const int ns = L / H;
+  for (int sidx = 0; sidx < ns; ++sidx)
+    for (int k = 0; k < nu; ++k) {
+      const int row0 = (sidx == 0) ? 2 * k : sidx * H - 2 * k;
+      const int nrows = (sidx == 0) ? H - 4 * k : H;
+      SWCHK(launch(k, row0, nrows, buf[(k + 1) & 1], buf[k & 1]));
+    }
+  for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k, buf[(k + 1) & 1], buf[k & 1]));
+  *result = buf[(nu - 1) & 1];
+  return 0;
+}
+
 // Even-odd post-smoothing of the stencil level (k_schur_step): on entry `start` holds the iterate
 // after the coarse correction (only its even half is used), on exit Xout the smoothed iterate.
 // `start` and `other` are the ping-pong pair chosen by the caller so that the last step lands in Xout.
@@ -1183,16 +1253,8 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
     hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0, di, bpc);
     KLAUNCH_CHECK();
   }
-  cplx* cur = start;
-  cplx* nxt = other;
-  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
-    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur,
-                       (const cplx*)bp, nxt, a, bpc);
-    KLAUNCH_CHECK();
-    std::swap(cur, nxt);
-  }
+  cplx* cur = nullptr;
+  SWCHK(schur_steps(h, lv, start, other, bp, nbp, &cur));
   {
     LaunchScope ls(h, T_SCHUR);
     hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, (const cplx*)cur, cur, a,
@@ -3126,6 +3188,11 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->fused_reduce = value != 0.0;
     return 0;
   }
+  if (std::strcmp(name, "eo_skew") == 0) {
+    if (value < -1.0 || value > 65536.0) return sw_fail(h, "eo_skew must be -1 (automatic), 0 (off) or a strip height");
+    h->eo_skew = (int)value;
+    return 0;
+  }
   if (std::strcmp(name, "lgmres_aug") == 0) {
     h->lgmres_aug = value != 0.0;
     return 0;
@@ -3388,18 +3455,9 @@ static int vcycle_even(sw_engine* h, Hier& H, const cplx* Bin, cplx* Xout, int n
   if (!(lv.P.order_even && h->p_even))
     return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
   SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, cur, nbp, T_P, cplx{0.0, 0.0}, true));
-  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
-  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
-  for (size_t k = 0; k < lv.w_eo.size(); ++k) {
-    a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
-    LaunchScope ls(h, T_SCHUR);
-    hipLaunchKernelGGL(swk::k_schur_step, grid, dim3(SW_BLOCK), 0, h->stream, (const cplx*)cur, Bin, nxt,
-                       a, bpc);
-    KLAUNCH_CHECK();
-    std::swap(cur, nxt);
-  }
-  if (cur != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
+  cplx* res = nullptr;
+  SWCHK(schur_steps(h, lv, cur, nxt, Bin, nbp, &res));
+  if (res != Xout) return sw_fail(h, "internal: even-odd smoother ended in the wrong buffer");
   return 0;
 }
 

@@ -149,6 +149,9 @@ struct StencilArgsT {
   int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
   typename scalar_of<C>::type w;   // MODE 2 relaxation weight
   int nt_store;        // non-temporal output stores
+  // even-odd kernels only: work on the lattice rows row0 .. row0 + nrows - 1 (mod L) instead of all of
+  // them (nrows = 0): the time-skewed order of the smoother's steps on lattices beyond the Infinity Cache
+  int row0 = 0, nrows = 0;
 };
 typedef StencilArgsT<cplx> StencilArgs;
 
@@ -316,12 +319,14 @@ __device__ __forceinline__ int wrap_m(int v, int L) { return (v == 0) ? L - 1 : 
 // site (x, y) of parity q for work item `it` in [0, V/2): the items walk x-tiles of tw lattice
 // columns (tw/2 sites of one parity per row), row by row inside a tile, so that the five lattice
 // rows a Schur step touches stay in the XCD's L2 on large lattices (as k_stencil's tile walk)
-__device__ __forceinline__ void eo_site(int it, int q, int L, int tw, int& x, int& y) {
+__device__ __forceinline__ void eo_site(int it, int q, int L, int tw, int row0, int rows, int& x, int& y) {
   const int ht = tw >> 1;
-  const int tile = it / (ht * L);
-  const int rem = it - tile * (ht * L);
-  y = rem / ht;
-  x = 2 * (tile * ht + (rem - y * ht)) + ((q + y) & 1);
+  const int tile = it / (ht * rows);
+  const int rem = it - tile * (ht * rows);
+  const int yl = rem / ht;
+  y = row0 + yl;
+  if (y >= L) y -= L;
+  x = 2 * (tile * ht + (rem - yl * ht)) + ((q + y) & 1);
 }
 
 // out(n) = alpha * Uv(n) + beta * (H src)(n)  on the sites n of parity Q; src on the other parity.
@@ -341,9 +346,10 @@ __global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const C* __restrict__ Uv,
   const int L = a.L, Vh = a.Vh, nbp = a.nbp;
   const size_t col = (size_t)chunk * 64 + lane;
   const int sh = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-  if (sh >= Vh) return;
+  const int rows = a.nrows > 0 ? a.nrows : L;
+  if (sh >= rows * (L >> 1)) return;
   int x, y;
-  eo_site(sh, Q, L, a.tile_w, x, y);
+  eo_site(sh, Q, L, a.tile_w, a.row0, rows, x, y);
   const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
   const C* S = src + col;
   SiteT<C> acc;
@@ -376,9 +382,10 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
   const int L = a.L, Vh = a.Vh, nbp = a.nbp;
   const size_t col = (size_t)chunk * 64 + lane;
   const int sh = __builtin_amdgcn_readfirstlane(sg * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-  if (sh >= Vh) return;
+  const int rows = a.nrows > 0 ? a.nrows : L;
+  if (sh >= rows * (L >> 1)) return;
   int x, y;
-  eo_site(sh, 0, L, a.tile_w, x, y);
+  eo_site(sh, 0, L, a.tile_w, a.row0, rows, x, y);
   const int xp = wrap_p(x, L), xm = wrap_m(x, L), yp = wrap_p(y, L), ym = wrap_m(y, L);
   const int xpp = wrap_p(xp, L), xmm = wrap_m(xm, L), ypp = wrap_p(yp, L), ymm = wrap_m(ym, L);
   const C* Xc = X + col;

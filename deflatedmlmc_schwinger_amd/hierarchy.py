@@ -625,7 +625,13 @@ TUNED_SOLVER_CFG_128 = {
     "eo_levels": [0, 1],        # levels smoothed on their even-odd Schur complement (half vectors)
     "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count
     "setup": "device",
-    "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1,
+    # device setup: three RELAXATION sweeps per new level (setup_tol = 0: a fixed 32 unpreconditioned
+    # GMRES(restart) steps each that damp the rough components of the random start vectors -- relaxation by
+    # design, not a solve that runs into an iteration cap), then one pass of CONVERGED inverse iteration
+    # preconditioned by the hierarchy itself (setup_refine; 2-3 iterations to 1e-2).  Replacing two of the
+    # three relaxation sweeps by a second converged pass was measured worse (12 instead of 11 outer
+    # iterations, gpurun_out r03b b_boot)
+    "setup_sweeps": 3, "setup_tol": 0.0, "setup_maxiter": 32, "setup_refine": 1,
     # the 4096-row level is solved exactly in even-odd reduced form: dense inverse of its 2048-row Schur
     # complement (formed on the device, sw_setup_direct_level) on the matrix cores -- four launches per
     # visit instead of the ~16 of ten Schur steps plus the level below (round 3: 355 -> 223 launches per
@@ -656,7 +662,8 @@ def synthetic_solver_cfg(L, nu0=10, setup="device"):
         cyc[-1] = [0, 14, 0]
     return {"coarsening": depth, "cycle": cyc, "smoother": "richardson", "restart": 3,
             "eo_levels": list(range(nsm)), "setup": setup,
-            "setup_sweeps": 3, "setup_tol": 0.1, "setup_maxiter": 32, "setup_refine": 1}
+            # (relaxation sweeps + one converged refinement pass: see TUNED_SOLVER_CFG_128)
+            "setup_sweeps": 3, "setup_tol": 0.0, "setup_maxiter": 32, "setup_refine": 1}
 
 
 def _site_prolongator(Al, Lf, hd, agg, nvec, tv, fine_level):

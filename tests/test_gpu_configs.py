@@ -363,3 +363,34 @@ def test_three_product_block_row_kernel_matches_the_four_product_one():
     X1 = _rand((5, n1), 99)
     assert _relerr(eng.apply_dirac(SOLVER_HID, 1, X1), (A1 @ X1.T).T) < 1e-13
     eng.close()
+
+
+def test_time_skewed_smoother_order_is_bit_identical():
+    """engine option eo_skew: the Schur steps of the lattice level's even-odd smoother applied strip by
+    strip in a time-skewed order (shrinking trapezoid, parallelograms, closing wedge on the periodic
+    lattice; what keeps the smoother's working set inside the Infinity Cache on lattices beyond it).
+    Same arithmetic per site in another order: the cycle and the solves must be BIT-identical to the
+    plain order -- strips of 32 and of 64 lattice rows on the 128^2 lattice (four and two strips), an odd
+    and an even number of steps (the ping-pong parity differs), full-system cycle and reduced-system solve."""
+    for nu in (8, 7):
+        A, tp, mg = _tuned128(extra={"cycle": [(0, nu, 0), (0, 10, 0)]})
+        eng = mg.engine
+        n = A.shape[0]
+        B = _rand((70, n), 19 + nu)
+        ref = None
+        try:
+            for H in (0, 32, 64):
+                eng.set_option("eo_skew", H)
+                eng.timers_reset()
+                Xc = eng.vcycle(SOLVER_HID, 0, B)                           # full-system cycle (eo_smooth)
+                launches = eng.launch_count()
+                Xs, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)       # reduced system (vcycle_even)
+                if ref is None:
+                    ref = (Xc, Xs, np.asarray(its), launches)
+                    continue
+                assert launches > ref[3]                                    # the strips really ran
+                assert np.array_equal(Xc, ref[0]), (nu, H)
+                assert np.array_equal(Xs, ref[1]) and np.array_equal(np.asarray(its), ref[2]), (nu, H)
+        finally:
+            eng.set_option("eo_skew", -1)
+        eng.close()

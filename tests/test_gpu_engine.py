@@ -834,6 +834,8 @@ def test_reference_faithful_cycle_reports_reference_iteration_counts():
         for k in range(nprobe):
             omg.level_nr = 0
             omg.solve(A, B[k], 1e-12)
+            print("reference-faithful cycle, %s probe %d: engine %d outer iterations, oracle (SciPy lgmres "
+                  "smoother) %d" % (name, k, int(its[k]), int(omg.num_iters)))
             assert abs(int(its[k]) - int(omg.num_iters)) <= 2, (name, k, its[k], omg.num_iters)
             assert _relerr(X[k], omg.x) < 1e-9
         if name == 'schwinger128':

@@ -40,11 +40,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nb", type=int, default=256, help="probes per engine stream per step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "0")),
                     help="concurrent probe batches (engine handles / HIP streams) per GPU; one since round "
                          "3: with the block level solved directly a single batch keeps the GPU busy and "
                          "its smoother's working set (201 MB) inside the 256 MB Infinity Cache, which three "
-                         "concurrent batches thrash (29.8k / 27.8k / 27.5k probe-samples/s for 1 / 2 / 3)")
+                         "concurrent batches thrash (29.8k / 27.8k / 27.5k probe-samples/s for 1 / 2 / 3); "
+                         "three for --workload mlmc, whose coarse-level solves are latency-bound and "
+                         "overlap (17.8k against 14.5k).  0: that default")
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
                     help="JSON solver-hierarchy override")
@@ -102,6 +104,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.streams <= 0:
+        args.streams = 3 if args.workload == "mlmc" else 1
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -184,6 +188,10 @@ KERNEL_CLASSES = (("k_stencil<0>", 8), ("k_stencil<1>", 9), ("k_stencil<2>", 10)
                   ("k_schur_step<0/1> (S x, b' - S x)", 16))
 MFMA_CLASSES = (("k_bsr_mfma(dense coarsest)", 11), ("k_bsr_mfma(level-1 operator)", 12),
                 ("k_bsr_mfma(level-2 operator)", 14))
+# classes whose algorithmic work the engine counts launch by launch while profiling: the MFMA classes
+# (complex multiply-adds x 8 flops) and the even-odd smoother of the lattice level (bytes: its launches
+# cover row windows of different heights in the time-skewed order)
+COUNTED_CLASSES = MFMA_CLASSES + (("k_schur_step", 15),)
 
 
 def kernel_rooflines(eng, levels, V, nbp, pmc=None, skip=(), three_products=True):
@@ -191,7 +199,7 @@ def kernel_rooflines(eng, levels, V, nbp, pmc=None, skip=(), three_products=True
     (profiling on): achieved = algorithmic bytes (or issued flops) per launch / average launch time
     (DESIGN.md section 5), sorted by the class's share of the batch."""
     kstats = {name: eng.kernel_stats(cls) for name, cls in KERNEL_CLASSES if name not in skip}
-    kwork = {name: eng.kernel_work(cls) for name, cls in MFMA_CLASSES}
+    kwork = {name: eng.kernel_work(cls) for name, cls in COUNTED_CLASSES}
     nc = levels[-1]
     algo = {
         "k_stencil<0>": ("hbm", V * (64.0 * nbp + 32.0)),              # SURVEY 8d

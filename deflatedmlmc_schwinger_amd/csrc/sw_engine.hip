@@ -13,6 +13,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -528,7 +529,8 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
     else if (NT3 == 2) B3_LAUNCH(MD, 2, NTB, SG); \
     else B3_LAUNCH(MD, 1, NTB, SG);               \
   } while (0)
-    if (!ntio3 && mode == 0 && want >= 8) B3_NT(0, false, 8);
+    if (!ntio3 && mode == 0 && want >= 16 && NT3 == 1 && op.bsr_KS % 16 == 0) B3_LAUNCH(0, 1, false, 16);
+    else if (!ntio3 && mode == 0 && want >= 8) B3_NT(0, false, 8);
     else if (mode == 0) { if (ntio3) B3_NT(0, true, 4); else B3_NT(0, false, 4); }
     else if (mode == 1) { if (ntio3) B3_NT(1, true, 4); else B3_NT(1, false, 4); }
     else { if (ntio3) B3_NT(3, true, 4); else B3_NT(3, false, 4); }
@@ -1188,6 +1190,8 @@ static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx
     const int items = (nrows > 0 ? nrows : L) * (L / 2);
     const int bpc = (items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
     LaunchScope ls(h, T_SCHUR);
+    // algorithmic bytes: three half-vector rows per even site and spin (x_e, b'_e in, x_e out) + links
+    if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
     hipLaunchKernelGGL(swk::k_schur_step, dim3(bpc * (nbp / 64)), dim3(SW_BLOCK), 0, h->stream, src, bp, dst, a,
                        bpc);
     KLAUNCH_CHECK();
@@ -1250,6 +1254,7 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
   const dim3 grid(bpc * (nbp / 64));
   {
     LaunchScope ls(h, T_SCHUR);
+    if (h->profiling) h->twork[T_SCHUR] += (double)a.Vh * (96.0 * nbp + 64.0);
     hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, Bin, bp, a, 1.0, di, bpc);
     KLAUNCH_CHECK();
   }
@@ -1257,6 +1262,7 @@ static int eo_smooth(sw_engine* h, Level& lv, const cplx* Bin, cplx* start, cplx
   SWCHK(schur_steps(h, lv, start, other, bp, nbp, &cur));
   {
     LaunchScope ls(h, T_SCHUR);
+    if (h->profiling) h->twork[T_SCHUR] += (double)a.Vh * (96.0 * nbp + 64.0);
     hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, Bin, (const cplx*)cur, cur, a,
                        di, di, bpc);
     KLAUNCH_CHECK();
@@ -2501,6 +2507,10 @@ static int gj_invert(sw_engine* h, cplx* D, int n) {
       hipLaunchKernelGGL(swk::k_gj_column_and_scale, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k,
                          (const cplx*)pvinv, colk);
       hipLaunchKernelGGL(swk::k_gj_update, gu, dim3(SW_BLOCK), 0, h->stream, D, n, k, (const cplx*)colk);
+      // keep the queue shallow: thousands of back-to-back launches without a host sync overran
+      // rocprofv3's per-dispatch counter buffers (FETCH_SIZE pass, n = 2048: segmentation fault inside
+      // the tool); a drain every 256 pivot steps costs nothing measurable
+      if ((k & 255) == 255) HIPCHK(hipStreamSynchronize(h->stream));
     }
     hipLaunchKernelGGL(swk::k_gj_unpermute, g1, dim3(SW_BLOCK), 0, h->stream, D, n, (const int*)pivs);
     KLAUNCH_CHECK();
@@ -3079,7 +3089,8 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     return 0;
   }
   if (std::strcmp(name, "bsr_stages") == 0 || std::strcmp(name, "dense_stages") == 0) {
-    if (value != 2.0 && value != 4.0 && value != 8.0) return sw_fail(h, "%s must be 2, 4 or 8", name);
+    if (value != 2.0 && value != 4.0 && value != 8.0 && !(value == 16.0 && name[0] == 'd'))
+      return sw_fail(h, "%s must be 2, 4 or 8 (dense_stages: or 16)", name);
     (name[0] == 'd' ? h->dense_stages : h->bsr_stages) = (int)value;
     return 0;
   }
@@ -3531,6 +3542,7 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
     const swk::FgTail tbeg = tail_begin(ws, 1);
     SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm, nullptr, nullptr, &tbeg));
     LaunchScope ls(h, T_SCHUR);
+    if (h->profiling) h->twork[T_SCHUR] += (double)a.Vh * (96.0 * nbp + 64.0);
     hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, B, B, bp, a, 1.0, di, bpc);
     KLAUNCH_CHECK();
   }
@@ -3632,6 +3644,7 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
   {
     // x_o = (b_o + H_oe x_e) / D
     LaunchScope ls(h, T_SCHUR);
+    if (h->profiling) h->twork[T_SCHUR] += (double)a.Vh * (96.0 * nbp + 64.0);
     hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, B, (const cplx*)X, X, a, di, di,
                        bpc);
     KLAUNCH_CHECK();
@@ -3800,7 +3813,12 @@ int sw_probes_generate(sw_engine* h, int slot, int level, int nb, int kind, uint
   // Asynchronous, on the generation stream: the call returns once the work is queued, the slot's `ready`
   // event orders it ahead of the sw_hutch_run that consumes the slot.  (While profiling, generation
   // stays on the solve stream so that the per-launch event pairs bracket it.)
-  hipStream_t gs = h->profiling ? h->stream : h->gen_stream;
+  // (SW_SINGLE_STREAM=1 keeps it on the solve stream as well: for tools that want one queue per process)
+  static const bool single_stream = [] {
+    const char* e = getenv("SW_SINGLE_STREAM");
+    return e && e[0] == '1';
+  }();
+  hipStream_t gs = (h->profiling || single_stream) ? h->stream : h->gen_stream;
   // 1. move the resident window to `pos`
   if (pos < h->mt_pos) {
     HIPCHK(hipMemcpyAsync(h->mt_win + (size_t)SW_MT_N * h->mt_cur, h->mt_win0,

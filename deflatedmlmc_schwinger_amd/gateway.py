@@ -89,10 +89,14 @@ def set_params(example_name):
 def _launch(example_name, driver):
     params = set_params(example_name)
     params['function_tol'] = _FUNCTION_TOL
-    # build-only key: concurrent probe batches per GPU (engine handles = HIP streams).  Three on the
-    # 128^2 lattice (a few GB of workspace each), one on the 16^2 toy problem; SW_ENGINES overrides.
+    # build-only key: concurrent probe batches per GPU (engine handles = HIP streams).  Measured on one
+    # MI355X (round 3): the deflated-Hutchinson flow is fastest with ONE batch at a time (its smoother's
+    # working set then stays inside the Infinity Cache: 32k against 27.5k probe-samples/s with three),
+    # the MLMC flow with three (its coarse-level solves are latency-bound and overlap: 18k against 14k
+    # level-0 difference probes/s); one on the 16^2 toy problem.  SW_ENGINES overrides.
     import os
-    params.setdefault('engines', int(os.environ.get("SW_ENGINES", 3 if example_name == 'schwinger128' else 1)))
+    default_engines = 3 if (example_name == 'schwinger128' and driver is EXAMPLE_002) else 1
+    params.setdefault('engines', int(os.environ.get("SW_ENGINES", default_engines)))
     return driver(params)
 
 

@@ -809,10 +809,12 @@ def test_stochastic_coarsest_level_build_only_option(p16, p128, capsys):
 
 def test_reference_faithful_cycle_reports_reference_iteration_counts():
     """with ref_smoother="gmres30x2" level-0 solves are preconditioned by
-    the REFERENCE hierarchy and MG.one_mg_step's own cycle (multigrid.py:369-447) with 2 x GMRES(30)
-    in place of lgmres(maxiter=2), so `function_iters` is the reference's count.  Checked against the
-    oracle's restatement (SciPy lgmres smoother + flexible GMRES): same outer iteration count up to
-    the one LGMRES augmentation vector this mode leaves out, same solution."""
+    the REFERENCE hierarchy and MG.one_mg_step's own cycle (multigrid.py:369-447) with the smoother the
+    reference calls, lgmres(maxiter=2) = GMRES(30) followed by an LGMRES cycle of 30 Arnoldi steps
+    augmented with the first cycle's correction (engine option lgmres_aug), so `function_iters` is the
+    reference's count.  Checked against the oracle's restatement (SciPy's own lgmres as the smoother +
+    flexible GMRES): same outer iteration count (+-1; measured: identical on all five probes), same
+    solution."""
     for name, nprobe in (('schwinger16', 4), ('schwinger128', 1)):
         params = gateway.set_params(name)
         params['function_tol'] = 1e-12
@@ -836,7 +838,7 @@ def test_reference_faithful_cycle_reports_reference_iteration_counts():
             omg.solve(A, B[k], 1e-12)
             print("reference-faithful cycle, %s probe %d: engine %d outer iterations, oracle (SciPy lgmres "
                   "smoother) %d" % (name, k, int(its[k]), int(omg.num_iters)))
-            assert abs(int(its[k]) - int(omg.num_iters)) <= 2, (name, k, its[k], omg.num_iters)
+            assert abs(int(its[k]) - int(omg.num_iters)) <= 1, (name, k, its[k], omg.num_iters)
             assert _relerr(X[k], omg.x) < 1e-9
         if name == 'schwinger128':
             assert 10 <= int(its[0]) <= 16          # 13 outer iterations per plain probe

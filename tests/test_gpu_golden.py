@@ -211,3 +211,51 @@ def test_benchmarked_path_full_batch_per_probe_parity():
           % (rel_s.max(), worst, abs(refs[worst]), itf_s.min(), itf_s.max(), itf.min(), itf.max()))
     assert rel_s.max() < 1e-10, (worst, float(rel_s.max()), float(abs(refs[worst])))
     assert np.all(np.abs(itf_s.astype(int) - itf.astype(int)) <= 1)
+
+
+def test_golden_128_full_batch_of_256_plain_probes():
+    """SURVEY 8c (>= 256 golden probes on 128^2): the whole first batch of BASELINE config 2 -- 256 plain
+    (k = 0) Hutchinson probes, seed 123456 -- against tests/golden/hutch128_plain256.json, which the
+    REFERENCE's own utils.one_defl_Hutch_step produced with exact LU solves
+    (tests/golden/make_golden_plain256.py).  Probes generated on the device, benchmarked solver hierarchy;
+    1e-10 relative for EVERY probe in the strict parity mode (stop_factor = 0.1), and at the reference's
+    own stopping point (default) 1e-10 relative to max(|e|, a tenth of the batch's median |e|)."""
+    from deflatedmlmc_schwinger_amd import hierarchy
+    from deflatedmlmc_schwinger_amd.engine import ProbeStream
+    gold = np.array([complex(a, b) for a, b in json.load(
+        open(os.path.join(HERE, "golden", "hutch128_plain256.json")))["hutch128_plain_seed123456_256"]])
+    assert gold.size == 256
+    assert np.max(np.abs(gold[:6] - _c("hutch128_plain_seed123456"))) < 1e-9     # same values as golden.json
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    params['solver_cfg'] = dict(hierarchy.TUNED_SOLVER_CFG_128)
+    params['nr_deflat_vctrs'] = 0
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "hutchinson")
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs=tp['accuracy_mg_eigvs'], sys_type='schwinger', params=tp)
+    eng = mg.engine
+    eng.set_deflation(None)
+    n = A.shape[0]
+    eng.stream_set(ProbeStream(123456).window())
+    eng.probes_generate(0, 0, 256, 0)
+    eng.probes_select(0)
+    eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
+    ests, itf, _ = eng.hutch_fetch()
+    floor = 0.1 * np.median(np.abs(gold))
+    scaled = np.abs(ests - gold) / np.maximum(np.abs(gold), floor)
+    assert scaled.max() < 1e-10, float(scaled.max())
+    try:
+        eng.set_option("stop_factor", 0.1)
+        eng.probes_select(0)
+        eng.hutch_run(MODE_HUTCHINSON, 0, 1e-12, 1000)
+        ests_s, _, _ = eng.hutch_fetch()
+    finally:
+        eng.set_option("stop_factor", 1.0)
+    rel = np.abs(ests_s - gold) / np.abs(gold)
+    k = int(np.argmax(rel))
+    print("256 golden plain probes: strict mode max rel %.3e (probe %d, |e| %.2f); default mode max scaled %.3e"
+          % (rel.max(), k, abs(gold[k]), scaled.max()))
+    assert rel.max() < 1e-10, (k, float(rel.max()), float(abs(gold[k])))
+    eng.close()

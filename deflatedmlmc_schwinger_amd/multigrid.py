@@ -176,6 +176,11 @@ class MG:
             for i, Cmat in rhsmaps.items():
                 eng.set_perm(i, int(levels[i].perm_shift))
                 eng.set_rhsmap(i, Cmat)
+        if params and params.get("stop_factor") is not None:
+            # build-only key: iterate every batch until its TRUE residuals are below stop_factor * tol
+            # (iteration counts are still reported at tol, multigrid.py:347-366); 1 = the reference's point
+            for eng in self.engines:
+                eng.set_option("stop_factor", float(params["stop_factor"]))
         # level-0 preconditioner
         cfg = params.get("solver_cfg") if params else None
         if (cfg is None or cfg == "auto") and lat is not None:

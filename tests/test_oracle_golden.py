@@ -61,6 +61,26 @@ def test_plain_probes_128_match_reference_utils(A128):
     assert abs(gold[0] - (-341.7528814576269 + 187.44897815730258j)) < 1e-9
 
 
+def test_plain_probes_128_match_the_256_probe_fixture(A128):
+    """the oracle's probe body against tests/golden/hutch128_plain256.json (the reference's own
+    one_defl_Hutch_step on the first 256 probes of seed 123456; the first 24 and the last 8 here)."""
+    import json
+    import os
+    gold = np.array([complex(a, b) for a, b in json.load(open(os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "golden", "hutch128_plain256.json")))[
+            "hutch128_plain_seed123456_256"]])
+    assert gold.size == 256
+    lu = rp.LUSolver(A128)
+    n = A128.shape[0]
+    PT = rp.pperm_matrix(n, 512).transpose()
+    np.random.seed(123456)
+    for k in range(256):
+        x = rp.rademacher(n)
+        if k < 24 or k >= 248:
+            e = rp.hutch_probe(x, lu, None, PT)
+            assert abs(e - gold[k]) < 1e-10 * abs(gold[k]), k
+
+
 def test_deflated_probes_128_match_reference_utils(A128):
     """deflation vectors come from ARPACK at tol 1e-9 on both sides, so 1e-8 relative."""
     n = A128.shape[0]

@@ -387,8 +387,9 @@ def run(args):
             res = list(pool.map(lambda e: run_one(e, s, generate, slot, prefetch), range(ne)))
         ests = np.concatenate([r[0] for r in res])
         itf = np.concatenate([r[1] for r in res])
-        stats = comm.allreduce_stats(swdist.local_stats(ests))
-        return ests, itf, stats
+        # this rank's {sum Re e, sum Im e, sum |e|^2, n}: accumulated over the steps and all-reduced ONCE
+        # per timed region (the path's single collective) -- not once per step
+        return ests, itf, swdist.local_stats(ests)
 
     def timed(fn):
         comm.barrier()
@@ -419,6 +420,8 @@ def run(args):
             ests, itf, stats = step(s, prefetch=(s < last))
             total[:] += stats
             iters_seen.append(int(itf.max()))
+        # the one collective of the path: trace sum / variance statistics over the ranks (RCCL over xGMI)
+        total[:] = comm.allreduce_stats(total)
     elapsed = timed(headline)
 
     # ---- secondary: the same steps with the probes resident in HBM before the clock starts
@@ -453,10 +456,12 @@ def run(args):
         ref_chk = []
 
         def f32_steps():
+            acc = np.zeros(4)
             for s in range(args.warmup, args.warmup + args.steps):
                 ests, itf, stats = step(s)
                 its32.append(int(itf.max()))
-                ref_chk.append(stats)
+                acc += stats
+            ref_chk.append(comm.allreduce_stats(acc))
         elapsed_f32 = timed(f32_steps)
         for e_ in engs:
             e_.set_option("precond_f32", 0)

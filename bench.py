@@ -409,6 +409,7 @@ def run(args):
     # ---- the timed region: K steps of generate + solve + reduce ---------------------------------
     for s in range(args.warmup):
         step(s)
+    comm.allreduce_stats(np.zeros(4))     # warm-up of the collective itself (lazy communicator set-up)
     total = np.zeros(4)
     iters_seen = []
 

@@ -7,6 +7,7 @@ infrastructure and is never imported from here).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import scipy.sparse as sp
@@ -42,6 +43,16 @@ def load_library():
             "HIP engine library not built: %s is missing (run `python -c 'import "
             "__graft_entry__ as g; g.build()'` or `make -C deflatedmlmc_schwinger_amd/csrc`)"
             % LIB_PATH)
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and "torch" not in sys.modules:
+        # A multi-rank launch will use torch.distributed (backend nccl = RCCL).  PyTorch bundles its own
+        # ROCm runtime: loaded AFTER this library it is mapped as a second HIP / HSA runtime in the process
+        # (same sonames, different files: /proc/self/maps shows both), loaded BEFORE it the dynamic loader
+        # resolves this library's libamdhip64.so.7 / libhsa-runtime64.so.1 to PyTorch's mapped copies --
+        # one runtime serving both.  So: torch first.
+        try:
+            import torch  # noqa: F401
+        except Exception:      # no torch: the engine runs on the system runtime alone
+            pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the box

@@ -104,6 +104,7 @@ struct KrylovWS {
   cplx* h2 = nullptr;   // [(m+2)][nbp]
   cplx* c1 = nullptr;   // [(m+2)][nbp] orthogonalisation coefficients svec_k^2 d_k
   cplx* nrm = nullptr;  // [nbp]
+  cplx* gram = nullptr; // [15][nbp] inner products of a restart cycle in Gram-matrix form (fgmres_eo_gram)
 };
 
 struct Level {
@@ -200,6 +201,8 @@ struct sw_engine {
   // (strips sized for the Infinity Cache where the smoother's three half vectors exceed it), 0 off,
   // > 0 strip height in lattice rows
   int eo_skew = -1;
+  // restart cycles of the even-odd reduced outer solve in Gram-matrix form (fgmres_eo_gram)
+  bool gram_cycle = true;
   bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
   bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
@@ -782,6 +785,31 @@ static int multidot(sw_engine* h, const swk::PtrListT<CV>& V, int K, const CV* W
   return 0;
 }
 
+// out[k][col] = u_a^H u_b for all pairs a <= b of NV vectors (k = a NV - a (a-1)/2 + (b-a)) in one pass;
+// the reduction is completed in the launch and `tail` (the Gram-cycle update) applied
+static int multigram(sw_engine* h, const PtrList& U, int NV, int n, int nbp, cplx* out, const swk::FgTail* tail) {
+  if (NV < 2 || NV > SW_GRAM_MAXL + 1) return sw_fail(h, "multigram: %d vectors out of range", NV);
+  const int K = NV * (NV + 1) / 2;
+  int P, rpb;
+  row_blocking(n, nbp, true, &P, &rpb);
+  const int ngroups = (P + SW_RED_GROUP - 1) / SW_RED_GROUP;
+  SWCHK(ensure_partial(h, (size_t)(P + ngroups) * K * nbp * sizeof(cplx)));
+  if (!fused_ok(h, P, nbp)) return sw_fail(h, "internal: the Gram cycle needs the in-launch reductions");
+  const swk::RedArgs ra = red_args(h, true, P, K, nbp, out, nullptr, nullptr);
+  const swk::FgTail tl = tail ? *tail : kNoTail;
+  dim3 grid(P, nbp / 64);
+  LaunchScope ls(h, T_DOTS);
+#define GR_CASE(NN) hipLaunchKernelGGL((swk::k_gram<NN>), grid, dim3(SW_BLOCK), 0, h->stream, U, n, nbp, rpb, \
+                                       h->partial, ra, tl)
+  if (NV == 2) GR_CASE(2);
+  else if (NV == 3) GR_CASE(3);
+  else if (NV == 4) GR_CASE(4);
+  else GR_CASE(5);
+#undef GR_CASE
+  KLAUNCH_CHECK();
+  return 0;
+}
+
 // Wout = Win + sign * sum_k coef[k] V_k ; optional nrm[col].x = ||Wout||^2
 template <class CV, class CW>
 static int multiaxpy(sw_engine* h, const swk::PtrListT<CV>& V, int K, const cplx* coef, double sign,
@@ -887,6 +915,7 @@ static int free_krylov(sw_engine* h, KrylovWS& w) {
   SWCHK(dev_free(h, w.h1)); w.h1 = nullptr;
   SWCHK(dev_free(h, w.h2)); w.h2 = nullptr;
   SWCHK(dev_free(h, w.nrm)); w.nrm = nullptr;
+  SWCHK(dev_free(h, w.gram)); w.gram = nullptr;
   w.m = w.n = w.nbp = 0;
   return 0;
 }
@@ -915,6 +944,7 @@ static int ensure_krylov(sw_engine* h, KrylovWS& w, int m, int n, int nbp, bool 
   SWCHK(dev_realloc(h, &w.h1, (size_t)(m + 2) * nbp));
   SWCHK(dev_realloc(h, &w.h2, (size_t)(m + 2) * nbp));
   SWCHK(dev_realloc(h, &w.nrm, (size_t)nbp));
+  SWCHK(dev_realloc(h, &w.gram, (size_t)((SW_GRAM_MAXL + 1) * (SW_GRAM_MAXL + 2) / 2) * nbp));
   w.sc.m = m;
   w.sc.nbp = nbp;
   w.m = m;
@@ -1151,12 +1181,51 @@ static int ensure_even_orders(sw_engine* h, Hier& H) {
   return 0;
 }
 
+static inline int* sink_slot(sw_engine* h);
+static bool f32_capable(const Hier& H, int level);
+
+// The K-cycle's inner iteration -- L steps of flexible GMRES from a zero guess, preconditioned by the cycle
+// of `level` -- in Gram-matrix form (see fgmres_eo_gram): directions without orthogonalisation, one pass for
+// all inner products, X = sum_j y_j z_j.  7 vector passes of BLAS-1 instead of 14 for L = 2.
+static int kcycle_gram(sw_engine* h, Hier& H, int level, const cplx* B, cplx* X, int L, KrylovWS& ws, int nbp) {
+  Level& lv = H.lv[level];
+  const size_t vec = (size_t)lv.n * nbp;
+  for (int j = 0; j < L; ++j) {
+    const cplx* vin = (j == 0) ? B : ws.V + vec * (j - 1);
+    SWCHK(vcycle(h, H, level, vin, ws.Z + vec * j, nbp));
+    SWCHK(apply_op(h, lv, 0, ws.Z + vec * j, nullptr, ws.V + vec * j, nbp));
+  }
+  PtrList pu;
+  pu.p[0] = B;
+  for (int j = 0; j < L; ++j) pu.p[j + 1] = ws.V + vec * j;
+  swk::FgTail tg{};
+  tg.kind = SW_TAIL_GRAM;
+  tg.s = ws.sc;
+  tg.j = L;
+  tg.h1 = ws.gram;
+  tg.tol = 0.0;
+  tg.tol_stop = 0.0;
+  tg.iter_base = 0;
+  tg.first_cycle = 1;
+  tg.notconv = sink_slot(h);
+  SWCHK(multigram(h, pu, L + 1, lv.n, nbp, ws.gram, &tg));
+  SWCHK(zero_vec(h, X, lv.n, nbp));
+  PtrList pz;
+  for (int q = 0; q < L; ++q) pz.p[q] = ws.Z + vec * q;
+  return multiaxpy(h, pz, L, ws.sc.ys, 1.0, X, X, lv.n, nbp, nullptr);
+}
+
 static int coarse_correction(sw_engine* h, Hier& H, int l, int nbp) {
   Level& lv = H.lv[l];
   Level& lc = H.lv[l + 1];
   const int last = H.nlevels - 1;
   if (lv.kcycle > 0 && l + 1 < last) {
     SWCHK(ensure_krylov(h, lc.kws, lv.kcycle, lc.n, nbp, false));
+    int P = 0, rpb = 0;
+    row_blocking(lc.n, nbp, true, &P, &rpb);
+    if (h->gram_cycle && lv.kcycle <= SW_GRAM_MAXL && fused_ok(h, P, nbp) &&
+        !(h->precond_f32 && f32_capable(H, l + 1)))
+      return kcycle_gram(h, H, l + 1, lc.b, lc.x, lv.kcycle, lc.kws, nbp);
     return fgmres(h, H, l + 1, lc.b, lc.x, 0.0, lv.kcycle, lv.kcycle, false, lc.kws, nbp, nullptr);
   }
   return vcycle(h, H, l + 1, lc.b, lc.x, nbp);
@@ -3204,6 +3273,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->eo_skew = (int)value;
     return 0;
   }
+  if (std::strcmp(name, "gram_cycle") == 0) {
+    h->gram_cycle = value != 0.0;
+    return 0;
+  }
   if (std::strcmp(name, "lgmres_aug") == 0) {
     h->lgmres_aug = value != 0.0;
     return 0;
@@ -3654,6 +3727,136 @@ static int fgmres_eo(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, 
   return 0;
 }
 
+// The same solve with restart cycles in GRAM-MATRIX form (option gram_cycle, default).  A cycle of L <= m
+// steps builds z_0 = M r, w_0 = S z_0, z_1 = M w_0, w_1 = S z_1, ... with NO inner products or
+// orthogonalisation in between -- the same Krylov space FGMRES(m) spans --, then one pass over [r, w_0 ..
+// w_{L-1}] yields all their inner products and the minimal-residual combination follows per probe from a
+// Cholesky-factorised L x L system (fg_gram_col, which also gives the residual norm of every nested
+// sub-cycle: per-probe iteration counts as before).  Per cycle of three: 12 half-vector passes of BLAS-1 and
+// residual instead of 29, 4 launches instead of 9.  Every cycle ends with the TRUE residual b' - S x, so the
+// convergence test always sees true residuals; the read-backs are per cycle, not per iteration: cycles run
+// unobserved until the previous batch's iteration count is within one cycle, then the residuals of all
+// probes come back (a few KB) and the last cycle is cut to the length they call for.
+static int fgmres_eo_gram(sw_engine* h, Hier& H, const cplx* B, cplx* X, double tol, int maxiter, int m,
+                          KrylovWS& ws, int nbp, int* iters_total) {
+  Level& lv = H.lv[0];
+  const int hid_idx = (int)(&H - &h->hier[0]);
+  const int hint = h->lazy_sync ? h->sync_hint[hid_idx][0] : 0;
+  const int n2 = lv.n / 2;
+  const size_t vec = (size_t)n2 * nbp;
+  const double tol_stop = tol * h->stop_factor;
+  SWCHK(ensure_level_ws(h, lv, nbp));
+  SWCHK(reset_slots(h));
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  const dim3 grid(bpc * (nbp / 64));
+  const double di = 1.0 / a.diag;
+  cplx* bp = ws.xacc;               // b'_e
+  {
+    // ||b|| of the FULL system fixes normb (the reference's stopping criterion); b'_e = b_e + H_eo b_o / D
+    PtrList pl;
+    pl.p[0] = B;
+    const swk::FgTail tbeg = tail_begin(ws, 1);
+    SWCHK(multidot(h, pl, 1, B, lv.n, nbp, ws.nrm, nullptr, nullptr, &tbeg));
+    LaunchScope ls(h, T_SCHUR);
+    if (h->profiling) h->twork[T_SCHUR] += (double)a.Vh * (96.0 * nbp + 64.0);
+    hipLaunchKernelGGL((swk::k_eo_hop<0>), grid, dim3(SW_BLOCK), 0, h->stream, B, B, bp, a, 1.0, di, bpc);
+    KLAUNCH_CHECK();
+  }
+  {
+    LaunchScope ls(h, T_AXPY);
+    HIPCHK(hipMemsetAsync(X, 0, vec * sizeof(cplx), h->stream));
+  }
+  std::vector<std::complex<double>> hrr(nbp), hrr0(nbp);
+  int done = 0;
+  bool converged = false;
+  const cplx* Rcur = bp;
+  int L = std::min(m, maxiter);
+  while (done < maxiter && !converged) {
+    L = std::max(1, std::min(L, std::min(m, maxiter - done)));
+    for (int j = 0; j < L; ++j) {
+      const cplx* vin = (j == 0) ? Rcur : ws.V + vec * (j - 1);
+      SWCHK(vcycle_even(h, H, vin, ws.Z + vec * j, nbp));
+      SWCHK(schur_apply(h, lv, 0, ws.Z + vec * j, nullptr, ws.V + vec * j, nbp));
+    }
+    int* slot = nullptr;
+    SWCHK(take_slot(h, &slot));
+    {
+      PtrList pu;
+      pu.p[0] = Rcur;
+      for (int j = 0; j < L; ++j) pu.p[j + 1] = ws.V + vec * j;
+      swk::FgTail tg{};
+      tg.kind = SW_TAIL_GRAM;
+      tg.s = ws.sc;
+      tg.j = L;
+      tg.h1 = ws.gram;
+      tg.tol = tol;
+      tg.tol_stop = tol_stop;
+      tg.iter_base = done;
+      tg.notconv = slot;
+      SWCHK(multigram(h, pu, L + 1, n2, nbp, ws.gram, &tg));
+    }
+    {
+      PtrList pz;
+      for (int q = 0; q < L; ++q) pz.p[q] = ws.Z + vec * q;
+      SWCHK(multiaxpy(h, pz, L, ws.sc.ys, 1.0, X, X, n2, nbp, nullptr));
+    }
+    done += L;
+    // the true residual: input of the next cycle and of the final check
+    SWCHK(schur_apply(h, lv, 1, X, bp, ws.rres, nbp));
+    Rcur = ws.rres;
+    // Observe?  Not while the previous batch's count says more than one further cycle is due.
+    const bool observe = tol_stop > 0.0 && (hint <= 0 || done + m >= hint || done >= maxiter);
+    int Lnext = m;
+    if (observe) {
+      int left = 0;
+      SWCHK(read_slot(h, slot, &left));
+      if (left == 0) {
+        converged = true;
+      } else {
+        // how many more steps do the slowest probes need at the rate this cycle achieved?
+        HIPCHK(hipMemcpy(hrr.data(), ws.sc.relres, sizeof(cplx) * nbp, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hrr0.data(), ws.sc.g, sizeof(cplx) * nbp, hipMemcpyDeviceToHost));
+        double need = 1.0;
+        for (int c = 0; c < nbp; ++c) {
+          const double r1 = hrr[c].real(), r0 = hrr0[c].real();
+          if (!(r1 >= tol_stop) || !(r0 > 0.0)) continue;
+          const double rate = std::pow(std::min(0.9, std::max(1e-6, r1 / r0)), 1.0 / L);   // per step
+          need = std::max(need, std::ceil(std::log(0.9 * tol_stop / r1) / std::log(rate)));
+        }
+        Lnext = (int)std::min<double>(m, need);
+      }
+    }
+    if (converged && h->verify) {
+      // (the decision above used the cycle's own estimate of |r_L|; the residual just formed is the true one)
+      PtrList pr;
+      pr.p[0] = ws.rres;
+      int* vslot = nullptr;
+      SWCHK(take_slot(h, &vslot));
+      const swk::FgTail tv = tail_verify(ws, tol, tol_stop, vslot);
+      SWCHK(multidot(h, pr, 1, ws.rres, n2, nbp, ws.nrm, nullptr, nullptr, &tv));
+      int left = 0;
+      SWCHK(read_slot(h, vslot, &left));
+      if (left != 0) {
+        converged = false;
+        Lnext = 1;
+      }
+    }
+    L = Lnext;
+  }
+  {
+    // x_o = (b_o + H_oe x_e) / D
+    LaunchScope ls(h, T_SCHUR);
+    if (h->profiling) h->twork[T_SCHUR] += (double)a.Vh * (96.0 * nbp + 64.0);
+    hipLaunchKernelGGL((swk::k_eo_hop<1>), grid, dim3(SW_BLOCK), 0, h->stream, B, (const cplx*)X, X, a, di, di,
+                       bpc);
+    KLAUNCH_CHECK();
+  }
+  if (iters_total) *iters_total = done;
+  h->sync_hint[hid_idx][0] = converged ? done : 0;
+  return 0;
+}
+
 // device-resident solve used by sw_solve and the probe drivers
 static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, double tol,
                      int maxiter, int nbp, int* total) {
@@ -3667,7 +3870,14 @@ static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, 
   }
   const int m = std::min(h->restart, std::max(1, maxiter));
   SWCHK(ensure_krylov(h, lv.sws, m, lv.n, nbp, true));
-  if (eo_solve_eligible(h, H, level0)) return fgmres_eo(h, H, B, X, tol, maxiter, m, lv.sws, nbp, total);
+  if (eo_solve_eligible(h, H, level0)) {
+    const bool k32 = h->precond_f32 && h->f32_krylov && f32_capable(H, 0);
+    int P = 0, rpb = 0;
+    row_blocking(lv.n / 2, nbp, true, &P, &rpb);
+    if (h->gram_cycle && !k32 && m <= SW_GRAM_MAXL && fused_ok(h, P, nbp))
+      return fgmres_eo_gram(h, H, B, X, tol, maxiter, m, lv.sws, nbp, total);
+    return fgmres_eo(h, H, B, X, tol, maxiter, m, lv.sws, nbp, total);
+  }
   return fgmres(h, H, level0, B, X, tol, maxiter, m, true, lv.sws, nbp, total);
 }
 

@@ -1461,6 +1461,8 @@ struct FgScalars {
 #define SW_TAIL_BEGIN 1
 #define SW_TAIL_HESS 2
 #define SW_TAIL_VERIFY 3
+#define SW_TAIL_GRAM 4
+#define SW_GRAM_MAXL 4       // longest restart cycle of the Gram-matrix form (5 vectors, 15 inner products)
 struct FgTail {
   int kind;
   FgScalars s;
@@ -1590,7 +1592,113 @@ __device__ __forceinline__ void fg_verify_col(const FgScalars& s, const cplx* __
   if (!(rr < tol_stop)) atomicAdd(notconv, 1);
 }
 
+// Restart cycle in Gram-matrix form (fgmres_eo_gram).  The cycle's L directions z_0 .. z_{L-1} and their
+// images w_j = S z_j are built WITHOUT any orthogonalisation (z_0 = M r_0, z_{j+1} = M w_j: the same Krylov
+// space as the Arnoldi process spans); ONE pass over [r_0, w_0 .. w_{L-1}] then yields all their inner
+// products G[a][b] = u_a^H u_b (a <= b, u_0 = r_0, u_{a+1} = w_a), and the minimal-residual combination
+// x += sum_j y_j z_j follows per probe from the normal equations (W^H W) y = W^H r_0 by a Cholesky
+// factorisation C C^H of the L x L matrix: forward substitution t = C^-1 W^H r_0 gives the residual norm of
+// EVERY nested sub-cycle for free (|r_j|^2 = |r_0|^2 - sum_{k<=j} |t_k|^2: the probe's iteration count is the
+// first j that passes tol, as with Givens rotations), back substitution gives y.  The basis is nearly
+// collinear (S M ~ I - E, |E| ~ 0.1: cond(W^H W) ~ 1e6 for L = 3), which costs the normal equations ~1e-10 of
+// relative accuracy in y -- irrelevant for a cycle that reduces the residual by ~1e-3 and is followed by a
+// TRUE residual; a pivot below 1e-13 of its diagonal entry truncates the cycle there.
+//   d[k][col]: the reduced inner products, k = a NV - a (a - 1) / 2 + (b - a), NV = L + 1.
+// Outputs: ys[j][col] = y_j (update coefficients), relres = |r_L| / |b|, g[0] = |r_0| / |b|.
+// init != 0 (a cycle from a zero guess that is a whole solve of its own, e.g. the K-cycle's inner iteration):
+// r_0 is the right-hand side, its norm becomes normb.
+__device__ __forceinline__ void fg_gram_col(const FgScalars& s, int L, const cplx* __restrict__ d, double tol,
+                                            double tol_stop, int iter_base, int* notconv, int init, int col) {
+  const int nbp = s.nbp, NV = L + 1;
+  auto G = [&](int a, int b) -> cplx { return d[(size_t)(a * NV - (a * (a - 1)) / 2 + (b - a)) * nbp + col]; };
+  const double g00 = fmax(G(0, 0).x, 0.0);
+  if (init) {
+    s.normb[col] = cmake(sqrt(g00), 0.0);
+    s.iters[col] = (g00 > 0.0) ? -1 : 0;
+  }
+  const double nb_ = s.normb[col].x;
+  const double rr0 = (nb_ > 0.0) ? sqrt(g00) / nb_ : 0.0;
+  s.g[col] = cmake(rr0, 0.0);
+  cplx C[SW_GRAM_MAXL][SW_GRAM_MAXL];
+  cplx t[SW_GRAM_MAXL];
+  double res2 = g00;
+  int Leff = 0;
+  // a probe whose residual is already two orders below the stopping tolerance (or has no right-hand side)
+  // takes no further part: y = 0
+  const bool done = !(nb_ > 0.0) || (s.iters[col] >= 0 && rr0 < 1.0e-2 * tol_stop) || g00 == 0.0;
+  double rr = rr0;
+  if (!done) {
+#pragma unroll
+    for (int j = 0; j < SW_GRAM_MAXL; ++j) {
+      if (j >= L) break;
+      // row j of the Cholesky factor of M[a][b] = w_a^H w_b = G(a + 1, b + 1)
+      double dj = G(j + 1, j + 1).x;
+      const double mjj = dj;
+#pragma unroll
+      for (int k = 0; k < SW_GRAM_MAXL; ++k) {
+        if (k >= j) break;
+        // M[j][k] = conj(M[k][j]) = conj(G(k + 1, j + 1))
+        cplx v = G(k + 1, j + 1);
+        v = cmake(v.x, -v.y);
+#pragma unroll
+        for (int i = 0; i < SW_GRAM_MAXL; ++i) {
+          if (i >= k) break;
+          // v -= C[j][i] conj(C[k][i])
+          const cplx a_ = C[j][i], b_ = C[k][i];
+          v = cmake(v.x - (a_.x * b_.x + a_.y * b_.y), v.y - (a_.y * b_.x - a_.x * b_.y));
+        }
+        const double ckk = C[k][k].x;
+        C[j][k] = cmake(v.x / ckk, v.y / ckk);
+        dj -= C[j][k].x * C[j][k].x + C[j][k].y * C[j][k].y;
+      }
+      if (!(dj > 1.0e-13 * mjj) || !(mjj > 0.0)) break;          // dependent direction: the cycle ends here
+      const double cjj = sqrt(dj);
+      C[j][j] = cmake(cjj, 0.0);
+      // t_j = ((W^H r_0)_j - sum_k C[j][k] t_k) / C[j][j],  (W^H r_0)_j = w_j^H r_0 = conj(G(0, j + 1))
+      cplx tj = G(0, j + 1);
+      tj = cmake(tj.x, -tj.y);
+#pragma unroll
+      for (int k = 0; k < SW_GRAM_MAXL; ++k) {
+        if (k >= j) break;
+        const cplx a_ = C[j][k], b_ = t[k];
+        tj = cmake(tj.x - (a_.x * b_.x - a_.y * b_.y), tj.y - (a_.x * b_.y + a_.y * b_.x));
+      }
+      t[j] = cmake(tj.x / cjj, tj.y / cjj);
+      res2 -= t[j].x * t[j].x + t[j].y * t[j].y;
+      Leff = j + 1;
+      rr = sqrt(fmax(res2, 0.0)) / nb_;
+      if (s.iters[col] < 0 && rr < tol) s.iters[col] = iter_base + j + 1;
+    }
+  }
+  // back substitution C^H y = t over the Leff directions that entered
+  cplx y[SW_GRAM_MAXL];
+#pragma unroll
+  for (int j = SW_GRAM_MAXL - 1; j >= 0; --j) {
+    y[j] = cmake(0.0, 0.0);
+    if (j >= Leff) continue;
+    cplx v = t[j];
+#pragma unroll
+    for (int k = SW_GRAM_MAXL - 1; k > 0; --k) {
+      if (k <= j || k >= Leff) continue;
+      // v -= conj(C[k][j]) y[k]
+      const cplx a_ = C[k][j], b_ = y[k];
+      v = cmake(v.x - (a_.x * b_.x + a_.y * b_.y), v.y - (a_.x * b_.y - a_.y * b_.x));
+    }
+    const double cjj = C[j][j].x;
+    y[j] = cmake(v.x / cjj, v.y / cjj);
+  }
+#pragma unroll
+  for (int j = 0; j < SW_GRAM_MAXL; ++j)
+    if (j < L) s.ys[(size_t)j * nbp + col] = y[j];
+  s.relres[col] = cmake(rr, 0.0);
+  if (!done && !(rr < tol_stop)) atomicAdd(notconv, 1);
+}
+
 __device__ __forceinline__ void fg_tail_col(const FgTail& t, int col) {
+  if (t.kind == SW_TAIL_GRAM) {
+    fg_gram_col(t.s, t.j, t.h1, t.tol, t.tol_stop, t.iter_base, t.notconv, t.first_cycle, col);
+    return;
+  }
   if (t.kind == SW_TAIL_BEGIN) fg_begin_col(t.s, t.h1, t.first_cycle, col);
   else if (t.kind == SW_TAIL_HESS)
     fg_hess_col(t.s, t.j, t.h1, t.h2, t.nrm2, t.tol, t.tol_stop, t.iter_base, t.pyth, t.notconv, col);
@@ -1823,6 +1931,53 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multidot(PtrListT<CV> V, int K, co
     }
     __syncthreads();
   }
+  if (ra.tick1) reduce_and_tail<6>(partial, K, nbp, ra, tail, &red[0][0][0]);
+}
+
+// All inner products of NV vectors with each other in ONE pass:  G[a][b] = u_a^H u_b, a <= b  (K = NV (NV+1) / 2
+// values, k = a NV - a (a - 1) / 2 + (b - a)); reduction completed in the launch, `tail` applied (fg_gram_col).
+// Replaces the j + 1 inner-product and orthogonalisation passes per Arnoldi step of a restart cycle.
+template <int NV>
+__global__ __launch_bounds__(SW_BLOCK) void k_gram(PtrList U, int n, int nbp, int rows_per_block,
+                                                   cplx* __restrict__ partial, RedArgs ra, FgTail tail) {
+  constexpr int K = NV * (NV + 1) / 2;
+  constexpr int KL = (K > 8) ? K : 8;          // (>= 6 * 4 * 64 values for the reduction tail)
+  __shared__ cplx red[3][KL][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.y * 64 + lane;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  cplx acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = cmake(0.0, 0.0);
+#pragma unroll 2
+  for (int r = r0 + wave; r < r1; r += SW_WAVES_PER_BLOCK) {
+    const size_t off = (size_t)r * nbp + col;
+    cplx u[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) u[a] = U.p[a][off];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < NV; ++a)
+#pragma unroll
+      for (int b = a; b < NV; ++b) cfmac(acc[k++], u[a], u[b]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave - 1][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      cplx v = acc[k];
+      v = cadd(v, red[0][k][lane]);
+      v = cadd(v, red[1][k][lane]);
+      v = cadd(v, red[2][k][lane]);
+      st_partial(&partial[((size_t)blockIdx.x * K + k) * nbp + col], v, ra.tick1 != nullptr);
+    }
+  }
+  __syncthreads();
   if (ra.tick1) reduce_and_tail<6>(partial, K, nbp, ra, tail, &red[0][0][0]);
 }
 

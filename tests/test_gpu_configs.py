@@ -394,3 +394,48 @@ def test_time_skewed_smoother_order_is_bit_identical():
         finally:
             eng.set_option("eo_skew", -1)
         eng.close()
+
+
+def test_gram_matrix_restart_cycles_equal_the_arnoldi_ones():
+    """engine option gram_cycle: the restart cycles of the even-odd reduced outer solve in Gram-matrix form
+    (directions built without orthogonalisation, ONE pass for all inner products, per-probe Cholesky solve of
+    the normal equations) against the Arnoldi / Givens form: same Krylov space, so the same solutions to
+    solver accuracy, true residuals below tol, per-probe iteration counts within one; mixed batches (zero
+    right-hand sides, an early-converging one, a ragged width), the strict stopping mode, and a batch that
+    must not converge within its iteration budget."""
+    A, tp, mg = _tuned128()
+    eng = mg.engine
+    n = A.shape[0]
+    B = _rand((70, n), 4711)
+    B[3] = 0.0                                    # zero right-hand side
+    B[5] = A @ _rand(n, 1) * 1e-3                 # ordinary, small norm
+    out = {}
+    try:
+        for flag in (1, 0):
+            eng.set_option("gram_cycle", flag)
+            for rep in range(2):                  # second solve: with the sync hint of the first
+                X, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+            nrm = np.linalg.norm(B.T, axis=0)
+            true = np.linalg.norm(B.T - A @ X.T, axis=0) / np.where(nrm > 0, nrm, 1.0)
+            assert true.max() < 5e-12, (flag, true.max())
+            assert np.all(X[3] == 0.0) and its[3] == 0
+            out[flag] = (X, np.asarray(its))
+        assert _relerr(out[1][0], out[0][0]) < 1e-10
+        assert np.max(np.abs(out[1][1] - out[0][1])) <= 1, (out[1][1], out[0][1])
+        eng.set_option("gram_cycle", 1)
+        eng.set_option("stop_factor", 0.1)
+        Xs, its_s, rr_s = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+        nrm = np.linalg.norm(B.T, axis=0)
+        true = np.linalg.norm(B.T - A @ Xs.T, axis=0) / np.where(nrm > 0, nrm, 1.0)
+        assert true.max() < 1.5e-13
+        assert np.max(np.abs(np.asarray(its_s) - out[1][1])) <= 1
+        eng.set_option("stop_factor", 1.0)
+        # iteration budget too small: reported, not raised; the iterate is the best found so far
+        Xn, its_n, rr_n = eng.solve(SOLVER_HID, 0, B[:8], 1e-12, 4)
+        assert rr_n[0] > 1e-12 and np.isfinite(Xn).all()
+        lu = rp.LUSolver(A)
+        assert _relerr(out[1][0][0], lu(B[0])) < 1e-9
+    finally:
+        eng.set_option("gram_cycle", 1)
+        eng.set_option("stop_factor", 1.0)
+    eng.close()

@@ -91,7 +91,7 @@ def _launch(example_name, driver):
     params['function_tol'] = _FUNCTION_TOL
     # build-only key: concurrent probe batches per GPU (engine handles = HIP streams).  Measured on one
     # MI355X (round 3): the deflated-Hutchinson flow is fastest with ONE batch at a time (its smoother's
-    # working set then stays inside the Infinity Cache: 32k against 27.5k probe-samples/s with three),
+    # working set then stays inside the Infinity Cache: 29.8k against 27.5k probe-samples/s with three),
     # the MLMC flow with three (its coarse-level solves are latency-bound and overlap: 18k against 14k
     # level-0 difference probes/s); one on the 16^2 toy problem.  SW_ENGINES overrides.
     import os

@@ -180,14 +180,19 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *                  (iteration counts are still reported at tol; 0.1 pins per-probe estimates to 1e-10
  *                  relative even where they cancel to small numbers); "fused_reduce" (1) inner products
  *                  completed inside the launch that forms their partial sums, FGMRES scalar updates
- *                  riding along; "lgmres_aug" (1) LGMRES augmentation vector in the reference-faithful
- *                  smoother's second cycle;
+ *                  riding along; "gram_cycle" (1) restart cycles of the even-odd reduced outer solve and the
+ *                  K-cycle's inner iteration in Gram-matrix form (directions without orthogonalisation, one
+ *                  pass for all inner products, per-probe Cholesky solve); "lgmres_aug" (1) LGMRES
+ *                  augmentation vector in the reference-faithful smoother's second cycle;
  *                  "lazy_sync" (1) convergence read-back only near the expected iteration count;
  *                  "dot_blocks" row blocks of the reducing BLAS-1 launches
  *   stencil level: "stencil_spw", "stencil_tile", "stencil_nt" (sites per wave, lattice tile width,
  *                  non-temporal stores); "p_even" (1) prolongation onto the even sites only ahead of an
- *                  even-odd smoother
- *   block levels:  "use_mfma" (1) fp64-MFMA block-row kernels vs grouped ELL; "mfma_ops", "mfma_tiles",
+ *                  even-odd smoother; "eo_skew" (-1) time-skewed strip order of the even-odd smoother's steps
+ *                  on lattices beyond the Infinity Cache (-1 automatic, 0 off, > 0 strip height in rows)
+ *   block levels:  "use_mfma" (1) fp64-MFMA block-row kernels vs grouped ELL; "mfma_3m" (1) three real
+ *                  matrix products per complex one (k_bsr_mfma3) instead of four; "mfma3_tiles" (0: by size)
+ *                  tiles of 16 probes per wave in that kernel; "mfma_ops", "mfma_tiles",
  *                  "mfma_small_tiles", "bsr_stages" / "dense_stages" (register pipeline depth), "bsr_nt",
  *                  "bsr_xreg", "bsr_sub", "dense_map", "ell_order"; complex64 twins "f32_tiles",
  *                  "f32_stages", "f32_dense_stages", "f32_splitk", "f32_pairs"

@@ -45,8 +45,8 @@ def parse():
                          "3: with the block level solved directly a single batch keeps the GPU busy and "
                          "its smoother's working set (201 MB) inside the 256 MB Infinity Cache, which three "
                          "concurrent batches thrash (29.8k / 27.8k / 27.5k probe-samples/s for 1 / 2 / 3); "
-                         "three for --workload mlmc, whose coarse-level solves are latency-bound and "
-                         "overlap (17.8k against 14.5k).  0: that default")
+                         "the same holds for --workload mlmc now that its coarse-level solves are direct "
+                         "(33.6k / 31.6k / 29.9k).  0: that default")
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--cfg", type=str, default=os.environ.get("SW_SOLVER_CFG", ""),
                     help="JSON solver-hierarchy override")
@@ -105,7 +105,7 @@ def launch_ranks(args):
 def main():
     args = parse()
     if args.streams <= 0:
-        args.streams = 3 if args.workload == "mlmc" else 1
+        args.streams = 1
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:

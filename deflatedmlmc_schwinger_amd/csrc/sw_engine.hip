@@ -116,6 +116,9 @@ struct Level {
   cplx* U2 = nullptr;
   EllOp A, P, R;
   EllOp Re;   // stencil level, even-odd reduced outer solve: R restricted to the even-site columns
+  // small level solved DIRECTLY (sw_setup_level_inverse): dense inverse of the level operator in block-row
+  // form; solve_dev applies it with one step of iterative refinement instead of iterating
+  EllOp dinv;
   int nu_pre = 0, nu_post = 3, kcycle = 0;
   // fixed-polynomial (Richardson) smoother: weights 1/theta_k; empty -> adaptive MR steps
   std::vector<std::complex<double>> w_pre, w_post;
@@ -203,6 +206,8 @@ struct sw_engine {
   int eo_skew = -1;
   // restart cycles of the even-odd reduced outer solve in Gram-matrix form (fgmres_eo_gram)
   bool gram_cycle = true;
+  // levels that carry the dense inverse of their operator (sw_setup_level_inverse) are solved with it
+  bool direct_small = true;
   bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
   bool stencil_nt = false;
   int stencil_tile = 0;   // 0: automatic
@@ -2153,6 +2158,7 @@ int sw_hier_begin(sw_engine* h, int hid, int nlevels) {
     SWCHK(free_op(h, lv.P));
     SWCHK(free_op(h, lv.R));
     SWCHK(free_op(h, lv.Re));
+    SWCHK(free_op(h, lv.dinv));
     for (int q = 0; q < 5; ++q) SWCHK(free_op(h, lv.eo_op[q]));
     SWCHK(dev_free(h, lv.rowmap));
     SWCHK(dev_free(h, lv.b)); SWCHK(dev_free(h, lv.x)); SWCHK(dev_free(h, lv.r));
@@ -2241,6 +2247,7 @@ int sw_set_csr(sw_engine* h, int hid, int level, int n, const int64_t* indptr,
   lv.n = n;
   std::vector<int> none;
   SWCHK(free_op(h, lv.A));
+  SWCHK(free_op(h, lv.dinv));      // an inverse of the previous operator is stale
   SWCHK(build_ell(h, lv.A, n, n, indptr, indices, (const std::complex<double>*)data, none, none));
   return build_bsr(h, lv.A, n, indptr, indices, (const std::complex<double>*)data, 0.6);
 }
@@ -2713,6 +2720,70 @@ int sw_setup_direct_level(sw_engine* h, int hid, int level) {
   SWCHK(dev_free(h, D));
   SWCHK(dev_free(h, d_rank));
   SWCHK(dev_free(h, d_E));
+  return 0;
+}
+
+// Dense inverse of a small level's operator (n <= 8192, n % 16 == 0; grouped-ELL operator from sw_set_csr, or the
+// block-row operator of a device-built level), formed on the device and kept as the level's direct solver:
+// solves that START at this level (the MLMC coarse solves A_c^-1 R x of utils.py:306-329 on the reference
+// hierarchy's small levels, the fine solves of its coarse difference levels) are then two applications of the
+// inverse around one residual -- x = A^-1 b, x += A^-1 (b - A x) -- instead of a multigrid-preconditioned FGMRES
+// of hundreds of tiny launches.  The refinement step takes the Gauss-Jordan inverse's residual (eps cond(A),
+// ~1e-11) below the solver tolerance.  The level keeps its operator, transfers and smoother for cycles
+// that merely pass through it.
+int sw_setup_level_inverse(sw_engine* h, int hid, int level) {
+  SWCHK(check_hier(h, hid, level, false));
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  Level& lv = H.lv[level];
+  const int n = lv.n;
+  if (lv.stencil) return sw_fail(h, "level %d is the lattice level", level);
+  if (n <= 0 || n % 16 || n > 8192) return sw_fail(h, "level %d: size %d not a multiple of 16 or above 8192", level, n);
+  const EllOp& A = lv.A;
+  if (!A.set) return sw_fail(h, "level %d has no operator", level);
+  cplx* D = nullptr;
+  SWCHK(dev_realloc(h, &D, (size_t)n * n));
+  HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
+  if (A.cols && A.vals) {
+    LaunchScope ls(h, T_OTHER);
+    const size_t total = (size_t)A.ngroups * A.K * A.G;
+    hipLaunchKernelGGL(swk::k_ell_to_dense, dim3((unsigned)((total + SW_BLOCK - 1) / SW_BLOCK)), dim3(SW_BLOCK), 0,
+                       h->stream, (const int*)A.cols, (const cplx*)A.vals, A.K, A.G, A.ngroups, n, D);
+    KLAUNCH_CHECK();
+  } else if (A.bsr_KS > 0 && !A.bsr_tmap) {
+    LaunchScope ls(h, T_OTHER);
+    const int items = (n / 16) * A.bsr_KS;
+    hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)A.bsr_vals, (const int*)A.bsr_kcol, n / 16,
+                       A.bsr_KS, n, D, (const int*)nullptr, (const int*)nullptr);
+    KLAUNCH_CHECK();
+  } else {
+    (void)dev_free(h, D);
+    return sw_fail(h, "level %d: operator in neither grouped-ELL nor full block-row form", level);
+  }
+  if (gj_invert(h, D, n) != 0) {
+    (void)dev_free(h, D);
+    return 1;
+  }
+  EllOp& op = lv.dinv;
+  SWCHK(free_op(h, op));
+  op.nrows = op.ncols = n;
+  const int KS = n / 4, RT = n / 16;
+  SWCHK(dev_realloc(h, &op.bsr_vals, (size_t)RT * KS * 64));
+  SWCHK(dev_realloc(h, &op.bsr_kcol, (size_t)RT * KS));
+  {
+    LaunchScope ls(h, T_OTHER);
+    const size_t items = (size_t)RT * KS;
+    hipLaunchKernelGGL(swk::k_dense_to_bsr, dim3((unsigned)((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK)),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)D, n, op.bsr_vals, op.bsr_kcol,
+                       (const int*)nullptr);
+    KLAUNCH_CHECK();
+  }
+  op.bsr_KS = KS;
+  op.set = true;
+  H.f32_valid = false;
+  SWCHK(stream_sync(h));
+  SWCHK(dev_free(h, D));
   return 0;
 }
 
@@ -3271,6 +3342,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   if (std::strcmp(name, "eo_skew") == 0) {
     if (value < -1.0 || value > 65536.0) return sw_fail(h, "eo_skew must be -1 (automatic), 0 (off) or a strip height");
     h->eo_skew = (int)value;
+    return 0;
+  }
+  if (std::strcmp(name, "direct_small") == 0) {
+    h->direct_small = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "gram_cycle") == 0) {
@@ -3857,6 +3932,11 @@ static int fgmres_eo_gram(sw_engine* h, Hier& H, const cplx* B, cplx* X, double 
   return 0;
 }
 
+static bool level_is_direct(sw_engine* h, Hier& H, int level) {
+  return h->direct_small && level < H.nlevels - 1 && !H.lv[level].stencil && H.lv[level].dinv.set &&
+         h->use_mfma;
+}
+
 // device-resident solve used by sw_solve and the probe drivers
 static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, double tol,
                      int maxiter, int nbp, int* total) {
@@ -3865,6 +3945,16 @@ static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, 
   if (level0 == H.nlevels - 1 && H.nlevels > 1) {
     // coarsest level: the dense inverse is the solve (multigrid.py:413-416)
     SWCHK(apply_coarsest(h, H, B, X, nbp));
+    if (total) *total = 1;
+    return 0;
+  }
+  if (level_is_direct(h, H, level0)) {
+    // x = A^-1 b ; x += A^-1 (b - A x): dense inverse on the matrix cores, one refinement step
+    SWCHK(ensure_level_ws(h, lv, nbp));
+    SWCHK(launch_bsr(h, lv.dinv, 0, B, nullptr, X, nbp, T_COARSEST, cplx{0.0, 0.0}));
+    SWCHK(apply_op(h, lv, 1, X, B, lv.r, nbp));
+    SWCHK(launch_bsr(h, lv.dinv, 0, lv.r, nullptr, lv.t, nbp, T_COARSEST, cplx{0.0, 0.0}));
+    SWCHK(vec_add(h, X, lv.t, X, lv.n, nbp));
     if (total) *total = 1;
     return 0;
   }
@@ -3908,7 +3998,7 @@ int sw_solve(sw_engine* h, int hid, int level0, int nb, const double* B, double*
   int total = 0;
   SWCHK(solve_dev(h, hid, level0, a, b, tol, maxiter, nbp, &total));
   SWCHK(unpack_host(h, lv, nb, b, X, nbp));
-  if (level0 == H.nlevels - 1 && H.nlevels > 1) {
+  if ((level0 == H.nlevels - 1 && H.nlevels > 1) || level_is_direct(h, H, level0)) {
     for (int j = 0; j < nb; ++j) {
       if (iters) iters[j] = 1;
       if (relres) relres[j] = 0.0;
@@ -4228,7 +4318,8 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
     SWCHK(solve_dev(h, fine_hid, level, xdef, h->pb_z, tol, maxiter, nbp, &total));
     SWCHK(dot_into(h, h->pb_x0, h->pb_z, n, nbp, h->pb_est));
     SWCHK(stream_sync(h));
-    if (level == H0.nlevels - 1 && H0.nlevels > 1) h->last_iters_f.assign(nb, 1);
+    if ((level == H0.nlevels - 1 && H0.nlevels > 1) || level_is_direct(h, h->hier[fine_hid], level))
+      h->last_iters_f.assign(nb, 1);
     else SWCHK(record_iters(h, &h->hier[fine_hid].lv[level].sws, total, h->last_iters_f, nb));
     h->last_iters_c.assign(nb, 0);
     return 0;
@@ -4252,7 +4343,8 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
   int total_f = 0, total_c = 0;
   SWCHK(solve_dev(h, fine_hid, level, xdef, h->pb_z, tol, maxiter, nbp, &total_f));
   SWCHK(stream_sync(h));
-  SWCHK(record_iters(h, &h->hier[fine_hid].lv[level].sws, total_f, h->last_iters_f, nb));
+  if (level_is_direct(h, h->hier[fine_hid], level)) h->last_iters_f.assign(nb, 1);
+  else SWCHK(record_iters(h, &h->hier[fine_hid].lv[level].sws, total_f, h->last_iters_f, nb));
   // xc = R x_def  (skip: R1 R0)             utils.py:298-304
   SWCHK(launch_ell(h, lv.R, 0, xdef, nullptr, h->pb_xc, nbp, T_R));
   const cplx* xc = h->pb_xc;
@@ -4263,7 +4355,7 @@ int sw_hutch_run(sw_engine* h, int mode, int level, double tol, int maxiter) {
   // y = A_c^-1 xc                            utils.py:306-329
   SWCHK(solve_dev(h, 0, lcoarse, xc, h->pb_y, tol, maxiter, nbp, &total_c));
   SWCHK(stream_sync(h));
-  if (lcoarse == H0.nlevels - 1) h->last_iters_c.assign(nb, 1);
+  if (lcoarse == H0.nlevels - 1 || level_is_direct(h, H0, lcoarse)) h->last_iters_c.assign(nb, 1);
   else SWCHK(record_iters(h, &H0.lv[lcoarse].sws, total_c, h->last_iters_c, nb));
   // w = P y (skip: P0 P1 y)                  utils.py:337-341
   const cplx* w;

@@ -2339,6 +2339,21 @@ __global__ __launch_bounds__(SW_BLOCK) void k_bsr_to_dense(const cplx* __restric
     D[((size_t)rt * 16 + (lane & 15)) * n + c + (lane >> 4)] = v;
 }
 
+// grouped-ELL operator -> dense row-major [n][n] (D zeroed by the caller; padding entries are zero-valued
+// and skipped); one thread per (group, k, g)
+__global__ __launch_bounds__(SW_BLOCK) void k_ell_to_dense(const int* __restrict__ cols, const cplx* __restrict__ vals,
+                                                           int K, int G, int ngroups, int n,
+                                                           cplx* __restrict__ D) {
+  const size_t i = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  const size_t total = (size_t)ngroups * K * G;
+  if (i >= total) return;
+  const int g = (int)(i % G);
+  const size_t gk = i / G;
+  const int grp = (int)(gk / K);
+  const cplx v = vals[i];
+  if (v.x != 0.0 || v.y != 0.0) D[((size_t)grp * G + g) * n + cols[gk]] = v;
+}
+
 // dense row-major [n][n] -> MFMA block-row form with every 4-column group (KS = n/4).
 // colsite (optional): dense column tile t stands for the level's site tile colsite[t]
 __global__ __launch_bounds__(SW_BLOCK) void k_dense_to_bsr(const cplx* __restrict__ D, int n,

@@ -89,6 +89,7 @@ def load_library():
     sig("sw_get_level_dense", i32, vp, i32, i32, vp)
     sig("sw_setup_invert_coarsest", i32, vp, i32)
     sig("sw_setup_direct_level", i32, vp, i32, i32)
+    sig("sw_setup_level_inverse", i32, vp, i32, i32)
     sig("sw_setup_arnoldi", i32, vp, i32, i32, i32, i32, C.c_uint64, vp)
     sig("sw_hier_end", i32, vp, i32)
     sig("sw_set_deflation", i32, vp, i32, vp)
@@ -145,7 +146,7 @@ EXPORTED_SYMBOLS = (
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
     "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator", "sw_setup_eo_operators", "sw_apply_eo_operator",
     "sw_get_level_bsr", "sw_setup_testvectors", "sw_setup_transfer",
-    "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_setup_direct_level", "sw_setup_arnoldi", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
+    "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_setup_direct_level", "sw_setup_level_inverse", "sw_setup_arnoldi", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_kernel_work", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -336,6 +337,11 @@ class Engine:
         """Dense inverse of block level `level`'s even-odd Schur complement, formed on the device and
         installed as the level's even-odd operator 4 (the level is then solved exactly)."""
         self._chk(self._lib.sw_setup_direct_level(self._h, hid, level), "sw_setup_direct_level")
+
+    def setup_level_inverse(self, hid, level):
+        """Dense inverse of a small level's operator (n <= 8192), formed on the device; solves that start
+        at this level are then two applications of it around one residual instead of an iteration."""
+        self._chk(self._lib.sw_setup_level_inverse(self._h, hid, level), "sw_setup_level_inverse")
 
     def setup_arnoldi(self, hid, level, which, degree, seed=2024):
         """(degree+1) x degree Hessenberg matrix of `degree` Arnoldi steps of the level operator

@@ -90,13 +90,12 @@ def _launch(example_name, driver):
     params = set_params(example_name)
     params['function_tol'] = _FUNCTION_TOL
     # build-only key: concurrent probe batches per GPU (engine handles = HIP streams).  Measured on one
-    # MI355X (round 3): the deflated-Hutchinson flow is fastest with ONE batch at a time (its smoother's
-    # working set then stays inside the Infinity Cache: 29.8k against 27.5k probe-samples/s with three),
-    # the MLMC flow with three (its coarse-level solves are latency-bound and overlap: 18k against 14k
-    # level-0 difference probes/s); one on the 16^2 toy problem.  SW_ENGINES overrides.
+    # MI355X (round 3): ONE batch at a time is fastest for both flows -- its smoother's working set then stays
+    # inside the Infinity Cache (deflated Hutchinson: 29.8k against 27.5k probe-samples/s with three at the
+    # time of that comparison; MLMC level-0 differences, with the small coarse levels solved directly:
+    # 33.6k / 31.6k / 29.9k for 1 / 2 / 3).  SW_ENGINES overrides.
     import os
-    default_engines = 3 if (example_name == 'schwinger128' and driver is EXAMPLE_002) else 1
-    params.setdefault('engines', int(os.environ.get("SW_ENGINES", default_engines)))
+    params.setdefault('engines', int(os.environ.get("SW_ENGINES", 1)))
     return driver(params)
 
 

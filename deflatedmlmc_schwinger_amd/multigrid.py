@@ -173,6 +173,15 @@ class MG:
                 eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A)
             eng.set_coarsest_inv(REF_HID, cinv)
             eng.hier_end(REF_HID)
+            # small intermediate levels of the reference hierarchy are solved directly (dense inverse formed
+            # on the device): the MLMC coarse solves and coarse difference levels start there.  Not in the
+            # reference-faithful mode, whose iteration counts must be the reference's.
+            direct_max = int(params.get("ref_direct_max_n", 4096)) if params else 4096
+            if not (params and params.get("ref_smoother") == "gmres30x2"):
+                for i in range(1, nlev - 1):
+                    n_i = levels[i].A.shape[0]
+                    if n_i <= direct_max and n_i % 16 == 0:
+                        eng.setup_level_inverse(REF_HID, i)
             for i, Cmat in rhsmaps.items():
                 eng.set_perm(i, int(levels[i].perm_shift))
                 eng.set_rhsmap(i, Cmat)

@@ -142,6 +142,13 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid);
  * that level's even-odd operator 4, with which the cycle solves the level exactly (option "eo_direct")
  * instead of smoothing it and visiting the levels below (multigrid.py:342-344,413-416 one level up). */
 int sw_setup_direct_level(sw_engine* h, int hid, int level);
+/* Dense inverse of a small level's OPERATOR (n <= 8192, multiple of 16), formed on the device and kept as the
+ * level's direct solver (option "direct_small", default on): solves that START at this level -- the MLMC
+ * coarse solves A_c^-1 R x of utils.py:306-329 on the reference hierarchy's small levels, the fine solves of
+ * its coarse difference levels (utils.py:292) -- become x = A^-1 b, x += A^-1 (b - A x) on the matrix cores
+ * instead of a multigrid-preconditioned FGMRES (multigrid.py:347-366); same solution to the solver tolerance,
+ * iteration count reported as 1. */
+int sw_setup_level_inverse(sw_engine* h, int hid, int level);
 /* Arnoldi relation for the smoother polynomial, on the device: `degree` steps (classical Gram-Schmidt
  * twice) of the level operator (which = 0) or of its even-odd Schur complement (which = 1) from a
  * pseudo-random start vector; Hout receives the (degree+1) x degree Hessenberg matrix, row-major

@@ -439,3 +439,48 @@ def test_gram_matrix_restart_cycles_equal_the_arnoldi_ones():
         eng.set_option("gram_cycle", 1)
         eng.set_option("stop_factor", 1.0)
     eng.close()
+
+
+def test_small_reference_levels_solved_directly_match_the_iterative_solves():
+    """sw_setup_level_inverse / option direct_small: the reference hierarchy's small intermediate levels
+    (2048 rows on schwinger128) carry the dense inverse of their operator, formed on the device; solves that
+    start there -- the MLMC coarse solve A_2^-1 R_1 R_0 x (utils.py:306-329) and the level-2 difference
+    level's fine solve -- are x = A^-1 b, x += A^-1 (b - A x) instead of a multigrid-preconditioned FGMRES.
+    Same solutions to the solver tolerance, true residual below it; MLMC estimates unchanged to 1e-10."""
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    tp = utils.trace_params_from_params(params, "mlmc")
+    tp['mlmc_deflat_vctrs'] = [0] * 3
+    mg = MG(A)
+    mg.setup(dof=tp['dof'], aggrs=tp['aggrs'], max_levels=tp['max_nr_levels'], dim=2,
+             acc_eigvs=tp['accuracy_mg_eigvs'], sys_type='schwinger', params=tp)
+    eng = mg.engine
+    levels = mg.ml.levels
+    assert [lev.A.shape[0] for lev in levels] == [32768, 8192, 2048, 512]
+    A2 = levels[2].A
+    B = _rand((70, 2048), 3)
+    out = {}
+    try:
+        for flag in (1, 0):
+            eng.set_option("direct_small", flag)
+            X, its, rr = eng.solve(REF_HID, 2, B, 1e-12, 2000)
+            true = np.linalg.norm(B.T - A2 @ X.T, axis=0) / np.linalg.norm(B.T, axis=0)
+            assert true.max() < 2e-12, (flag, true.max())
+            out[flag] = (X, np.asarray(its))
+            np.random.seed(31)
+            probes = utils.draw_probes(8, A.shape[0])
+            e_skip, _, itc = eng.hutch_batch(MODE_MLMC_SKIP, 0, probes, 1e-12, 1000)
+            np.random.seed(32)
+            probes2 = utils.draw_probes(8, 2048)
+            e_l2, itf2, _ = eng.hutch_batch(MODE_MLMC, 2, probes2, 1e-12, 1000)
+            out[(flag, "e")] = (e_skip, e_l2, np.asarray(itc), np.asarray(itf2))
+    finally:
+        eng.set_option("direct_small", 1)
+    assert np.all(out[1][1] == 1) and out[0][1].max() > 1               # direct: one "iteration"; iterative: many
+    assert _relerr(out[1][0], out[0][0]) < 1e-10
+    assert np.all(out[(1, "e")][2] == 1) and np.all(out[(1, "e")][3] == 1)
+    scale = np.maximum(np.abs(out[(0, "e")][0]), 1.0)
+    assert np.max(np.abs(out[(1, "e")][0] - out[(0, "e")][0]) / scale) < 1e-9
+    assert np.max(np.abs(out[(1, "e")][1] - out[(0, "e")][1]) / np.maximum(np.abs(out[(0, "e")][1]), 1.0)) < 1e-9
+    eng.close()

@@ -539,10 +539,13 @@ def run(args):
                     "synthetic Rademacher probes (MT19937 seed 123456, generated on the GPU inside "
                     "the timed region) on a synthetic random U(1) gauge configuration (seed 2024)",
             "config": {
-                "workload": "schwinger128, %d x %d probes/GPU/step (%d concurrent multi-RHS batches "
-                            "of %d on separate HIP streams), deflated Hutchinson (k=8, Pperm shift "
-                            "512), tuned solver hierarchy %s built on the GPU, fp64, tol %.0e"
-                            % (ne, nb, ne, nb, "/".join(str(v) for v in levels), args.tol)
+                "workload": "schwinger128, %d x %d probes/GPU/step (%d multi-RHS batch(es) of %d at a time, "
+                            "one HIP stream each), deflated Hutchinson (k=8, Pperm shift 512), tuned solver "
+                            "hierarchy %s built on the GPU -- a TWO-LEVEL cycle in effect: the lattice level "
+                            "smoothed even-odd, the %d-row level solved exactly (dense inverse of its "
+                            "even-odd Schur complement); the last level serves the setup only --, fp64, tol %.0e"
+                            % (ne, nb, ne, nb, "/".join(str(v) for v in levels),
+                               levels[1] if len(levels) > 1 else 0, args.tol)
                             if args.workload == "hutchinson" else
                             "BASELINE config 2 as written: schwinger128, %d x %d probes/GPU/step as "
                             "multi-RHS batches, plain Hutchinson (k=0, Pperm shift 512), 2-level "

@@ -541,11 +541,13 @@ def run(args):
             "config": {
                 "workload": "schwinger128, %d x %d probes/GPU/step (%d multi-RHS batch(es) of %d at a time, "
                             "one HIP stream each), deflated Hutchinson (k=8, Pperm shift 512), tuned solver "
-                            "hierarchy %s built on the GPU -- a TWO-LEVEL cycle in effect: the lattice level "
-                            "smoothed even-odd, the %d-row level solved exactly (dense inverse of its "
-                            "even-odd Schur complement); the last level serves the setup only --, fp64, tol %.0e"
+                            "hierarchy %s built on the GPU%s, fp64, tol %.0e"
                             % (ne, nb, ne, nb, "/".join(str(v) for v in levels),
-                               levels[1] if len(levels) > 1 else 0, args.tol)
+                               (" -- a TWO-LEVEL cycle in effect: the lattice level smoothed even-odd, the "
+                                "%d-row level solved exactly (dense inverse of its even-odd Schur complement); "
+                                "the last level serves the setup only --" % levels[1])
+                               if ((mg.solver_info or {}).get("cfg") or {}).get("direct_levels") == [1] else "",
+                               args.tol)
                             if args.workload == "hutchinson" else
                             "BASELINE config 2 as written: schwinger128, %d x %d probes/GPU/step as "
                             "multi-RHS batches, plain Hutchinson (k=0, Pperm shift 512), 2-level "

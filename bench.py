@@ -167,8 +167,11 @@ def build_problem(workload, args, device_index, engines):
         params['max_nr_levels'] = 2
         params['nr_deflat_vctrs'] = 0
         params['use_solver_hierarchy'] = False
-        params['ref_smoother'] = 'richardson'
-        params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "48"))
+        # smoother of the lattice level: a degree-64 polynomial on its even-odd Schur complement (half vectors,
+        # outer solve on the reduced system): 4.1k probe-samples/s at 12 iterations against 1.6k at 22 with the
+        # degree-48 polynomial on the full operator (profiles/r03_ab_sessions.txt, r03s)
+        params['ref_smoother'] = os.environ.get("SW_CONFIG2_SMOOTHER", "eo")
+        params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "64"))
         params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "16"))
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
     tp = utils.trace_params_from_params(params, "mlmc" if workload == "mlmc" else "hutchinson")
@@ -552,8 +555,10 @@ def run(args):
                             "BASELINE config 2 as written: schwinger128, %d x %d probes/GPU/step as "
                             "multi-RHS batches, plain Hutchinson (k=0, Pperm shift 512), 2-level "
                             "multigrid 32768 -> 8192 (reference aggregation: 32-row aggregates, 4 test "
-                            "vectors x 2; dense 8192^2 coarse inverse on fp64 MFMA), fp64, tol %.0e"
-                            % (ne, nb, args.tol) if args.workload == "config2" else
+                            "vectors x 2; dense 8192^2 coarse inverse on fp64 MFMA; lattice-level smoother %s "
+                            "degree %d), fp64, tol %.0e"
+                            % (ne, nb, tp.get("ref_smoother"), tp.get("ref_cycle_post"), args.tol)
+                            if args.workload == "config2" else
                             "synthetic %dx%d random U(1) lattice (sigma 0.204, m -0.05), %d x %d plain "
                             "Hutchinson probes/GPU/step, GPU-side adaptive MG setup, fp64, tol %.0e"
                             % (L, L, ne, nb, args.tol) if synthetic else
@@ -630,6 +635,8 @@ def other_configs(args, mg, n, device_index):
                           "8192 (reference aggregation), dense 8192^2 coarse inverse on fp64 MFMA",
                           mg2, MODE_HUTCHINSON, args.nb, n2, args.tol, 2, 1)
             r["setup_s"] = ts
+            r["smoother"] = {"kind": tp2.get("ref_smoother"), "degree": tp2.get("ref_cycle_post"),
+                             "restart": tp2.get("solver_restart")}
             return r
         finally:
             for e_ in mg2.engines:

@@ -173,6 +173,22 @@ class MG:
                 eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A)
             eng.set_coarsest_inv(REF_HID, cinv)
             eng.hier_end(REF_HID)
+            if params and params.get("ref_smoother") == "eo" and nlev > 1 and lat is not None:
+                nu_post = int(params.get("ref_cycle_post", 4))
+                # even-odd Schur-complement polynomial on the lattice level of the REFERENCE hierarchy
+                # (half vectors, S four times better conditioned than A; outer solves then run on the
+                # even-odd reduced system): weights from a device-side Arnoldi run on S
+                key = ("ref-eo", nu_post)
+                if key not in self._ref_weights:
+                    if nu_post <= 32:
+                        self._ref_weights[key] = _hier.weights_from_hessenberg(
+                            eng.setup_arnoldi(REF_HID, 0, 1, nu_post))
+                    else:
+                        # beyond the device Arnoldi's 32 vectors: the same fit through the C ABI
+                        from . import setup_gpu as _sg
+                        self._ref_weights[key] = _hier.smoother_weights(
+                            _sg._EngineSchur(eng, REF_HID, lat[0], lat[1]), nu_post)
+                eng.set_eo_smoother(REF_HID, 0, self._ref_weights[key])
             # small intermediate levels of the reference hierarchy are solved directly (dense inverse formed
             # on the device): the MLMC coarse solves and coarse difference levels start there.  Not in the
             # reference-faithful mode, whose iteration counts must be the reference's.

@@ -112,14 +112,17 @@ def test_golden_16_permuted_level_skipping():
     assert np.max(np.abs(ests - gold)) / scale < 1e-10
 
 
-def test_config2_as_written_two_level_plain_hutchinson():
+@pytest.mark.parametrize("smoother,degree,restart", [("richardson", 7, 12), ("eo", 24, 16)])
+def test_config2_as_written_two_level_plain_hutchinson(smoother, degree, restart):
     """BASELINE config 2 literally: schwinger128, plain (k = 0) Hutchinson, 2-level multigrid
     32768 -> 8192 built with the reference's aggregation (multigrid.py:192-262: 32-row aggregates,
     4 test vectors x 2), dense 8192^2 coarse inverse on the fp64 matrix cores.  Per-probe values
-    against the reference's own golden values (LU solves) at 1e-10."""
+    against the reference's own golden values (LU solves) at 1e-10.  Smoother of the lattice level: a
+    polynomial on the full operator, or (what bench.py's config-2 record uses) on its even-odd Schur
+    complement with the outer solve on the reduced system."""
     A, tp, mg, tr1 = _setup('schwinger128', 0, {'max_nr_levels': 2, 'use_solver_hierarchy': False,
-                                                'ref_smoother': 'richardson', 'ref_cycle_post': 7,
-                                                'solver_restart': 12})
+                                                'ref_smoother': smoother, 'ref_cycle_post': degree,
+                                                'solver_restart': restart})
     assert [lev.A.shape[0] for lev in mg.ml.levels] == [32768, 8192]
     assert tr1 == 0.0
     n = A.shape[0]

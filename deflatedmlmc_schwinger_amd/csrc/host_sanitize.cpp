@@ -4,6 +4,7 @@
 // Exit code 0 = all checks passed and the sanitizers saw nothing.
 #include "../../include/schwinger_hip.h"
 #include "sw_pack.hpp"
+#include "sw_poly.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -209,11 +210,49 @@ static void test_mt() {
   CHECK(sw_mt_from_state(nullptr, 0) == nullptr, "null key accepted");
 }
 
+// product form of the smoother polynomials (sw_poly.hpp): q(z) = (1 - prod (1 - w_k z)) / z against
+// beta prod (1 - u_j z) at points of the spectral region, degrees as the solvers use them (8, 10) and the
+// degree-64 polynomial of BASELINE config 2's even-odd smoother; degenerate inputs
+static void test_poly(std::mt19937& rng) {
+  typedef std::complex<long double> lc;
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  for (int nu : {3, 7, 8, 10, 24, 64}) {
+    // weights 1 / theta_k, theta_k Chebyshev-like points of [0.25, 7.6] pushed off the real axis
+    std::vector<std::complex<double>> w, u;
+    for (int k = 0; k < nu; ++k) {
+      const double c = std::cos(M_PI * (k + 0.5) / nu);
+      const std::complex<double> th(3.925 + 3.675 * c, 0.3 * (U(rng) - 0.5));
+      w.push_back(1.0 / th);
+    }
+    std::shuffle(w.begin(), w.end(), rng);
+    std::complex<double> beta;
+    CHECK(swp::product_form(w, u, beta), "product form not found");
+    CHECK((int)u.size() == nu - 1, "product form: number of factors");
+    double worst = 0.0;
+    for (int t = 0; t < 50; ++t) {
+      const lc z(0.2 + 7.6 * U(rng), 0.4 * (U(rng) - 0.5));
+      lc p = 1.0L;
+      for (auto& wk : w) p *= (lc(1.0L) - lc(wk.real(), wk.imag()) * z);
+      const lc q = (lc(1.0L) - p) / z;
+      lc v(beta.real(), beta.imag());
+      for (auto& uj : u) v *= (lc(1.0L) - lc(uj.real(), uj.imag()) * z);
+      worst = std::max(worst, (double)(std::abs(v - q) / std::max(std::abs(q), (long double)1e-3L)));
+    }
+    CHECK(worst < 1e-8, "product form does not reproduce q");
+  }
+  std::vector<std::complex<double>> w2 = {{0.5, 0.0}, {0.25, 0.0}}, u2;
+  std::complex<double> b2;
+  CHECK(!swp::product_form(w2, u2, b2) && u2.empty(), "degree below 3 accepted");
+  std::vector<std::complex<double>> w3 = {{0.5, 0.0}, {0.0, 0.0}, {0.25, 0.1}};
+  CHECK(!swp::product_form(w3, u2, b2) && u2.empty(), "zero weight accepted");
+}
+
 int main() {
   std::mt19937 rng(20240);
   test_ell(rng);
   test_bsr(rng);
   test_mt();
+  test_poly(rng);
   if (fails) {
     std::printf("host_sanitize: %d check(s) failed\n", fails);
     return 1;

@@ -5,6 +5,7 @@
 #include "../../include/schwinger_hip.h"
 #include "sw_kernels.hpp"
 #include "sw_pack.hpp"
+#include "sw_poly.hpp"
 
 #include <dlfcn.h>
 
@@ -128,6 +129,10 @@ struct Level {
   // MFMA block-row form, eo_op[0] = S (even x even, 9-point), [1] = F = A_eo D_oo^-1,
   // [2] = G = D_oo^-1, [3] = Hb = D_oo^-1 A_oe
   std::vector<std::complex<double>> w_eo;
+  // the same smoother polynomial in product form (swp::product_form): x + q(S)(b' - S x) with
+  // q(z) = (1 - prod_k (1 - w_k z)) / z = q_beta prod_j (1 - q_w[j] z); empty when not available
+  std::vector<std::complex<double>> q_w;
+  std::complex<double> q_beta;
   EllOp eo_op[5];   // [4] (optional): the DENSE inverse of S over the even sites' rows -- the level's Schur
                     // steps, and everything below the level, are then replaced by one application of it
   std::vector<int> h_rowmap;  // natural -> internal (empty: identity)
@@ -206,6 +211,9 @@ struct sw_engine {
   int eo_skew = -1;
   // restart cycles of the even-odd reduced outer solve in Gram-matrix form (fgmres_eo_gram)
   bool gram_cycle = true;
+  // even-odd smoother of the reduced-system cycle in product form (schur_product_steps): 2 nu + 2 half-vector
+  // passes instead of 3 nu
+  bool eo_product = true;
   // levels that carry the dense inverse of their operator (sw_setup_level_inverse) are solved with it
   bool direct_small = true;
   bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
@@ -1238,6 +1246,35 @@ static int coarse_correction(sw_engine* h, Hier& H, int l, int nbp) {
 
 static swk::StencilArgs eo_stencil_args(sw_engine* h, Level& lv, int nbp);
 
+// One k_schur_step launch on the stencil level (fp64) on the lattice rows a.row0 .. a.row0 + a.nrows - 1
+// (a.nrows = 0: all)
+template <int MODE>
+static int launch_schur_step(sw_engine* h, swk::StencilArgs& a, const cplx* src, const cplx* bp, cplx* dst,
+                             int nbp) {
+  const int items = (a.nrows > 0 ? a.nrows : a.L) * (a.L / 2);
+  const int bpc = (items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
+  hipLaunchKernelGGL((swk::k_schur_step<cplx, MODE>), dim3(bpc * (nbp / 64)), dim3(SW_BLOCK), 0, h->stream, src,
+                     bp, dst, a, bpc);
+  KLAUNCH_CHECK();
+  return 0;
+}
+
+// strip height of the time-skewed order for nu launches that each reach two lattice rows (0: plain order)
+static int skew_height(sw_engine* h, Level& lv, int nu, int nbp) {
+  const int L = lv.L;
+  int H = 0;
+  if (h->eo_skew != 0 && nu >= 2) {
+    const double row_bytes = (double)(L / 2) * 2.0 * sizeof(cplx) * nbp;        // one lattice row of a half vector
+    if (h->eo_skew > 0) H = h->eo_skew;
+    else if (3.0 * row_bytes * L > 208.0e6) {
+      H = 1;
+      while (2 * H <= L / 2 && 3.0 * row_bytes * (2 * H) <= 208.0e6) H *= 2;
+    }
+    if (H > 0 && (L % H != 0 || L / H < 2 || H <= 4 * (nu - 1) || (H & 1))) H = 0;
+  }
+  return H;
+}
+
 // The nu Schur steps of an even-odd smoothing pass on the stencil level,
 //   x_e <- x_e + w_k (bp - S x_e),  k = 0 .. nu-1,
 // ping-ponging between `cur` (the iterate on entry) and `nxt`; *result = the buffer the last step wrote.
@@ -1262,26 +1299,12 @@ static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx
     a.row0 = row0;
     a.nrows = nrows;
     const int items = (nrows > 0 ? nrows : L) * (L / 2);
-    const int bpc = (items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
     LaunchScope ls(h, T_SCHUR);
     // algorithmic bytes: three half-vector rows per even site and spin (x_e, b'_e in, x_e out) + links
     if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
-    hipLaunchKernelGGL(swk::k_schur_step, dim3(bpc * (nbp / 64)), dim3(SW_BLOCK), 0, h->stream, src, bp, dst, a,
-                       bpc);
-    KLAUNCH_CHECK();
-    return 0;
+    return launch_schur_step<2>(h, a, src, bp, dst, nbp);
   };
-  // strip height: 0 = no skewing
-  int H = 0;
-  if (h->eo_skew != 0 && nu >= 2) {
-    const double row_bytes = (double)(L / 2) * 2.0 * sizeof(cplx) * nbp;        // one lattice row of a half vector
-    if (h->eo_skew > 0) H = h->eo_skew;
-    else if (3.0 * row_bytes * L > 208.0e6) {
-      H = 1;
-      while (2 * H <= L / 2 && 3.0 * row_bytes * (2 * H) <= 208.0e6) H *= 2;
-    }
-    if (H > 0 && (L % H != 0 || L / H < 2 || H <= 4 * (nu - 1) || (H & 1))) H = 0;
-  }
+  const int H = skew_height(h, lv, nu, nbp);      // 0 = no skewing
   if (H == 0) {
     for (int k = 0; k < nu; ++k) {
       SWCHK(launch(k, 0, 0, cur, nxt));
@@ -1301,6 +1324,57 @@ static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx
     }
   for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k, buf[(k + 1) & 1], buf[k & 1]));
   *result = buf[(nu - 1) & 1];
+  return 0;
+}
+
+// The same smoothing pass in PRODUCT FORM.  The nu steps above give x + q(S)(b' - S x) with the polynomial
+// q(z) = (1 - prod_k (1 - w_k z)) / z of degree nu - 1; written as q(z) = beta prod_j (1 - u_j z) (Level::q_w,
+// swp::product_form) the pass becomes
+//   v = b' - S x              (k_schur_step<1>: x, b' in, v out     -- 3 half-vector passes)
+//   v <- v - u_j S v          (k_schur_step<3>, j = 0 .. nu-3       -- 2 passes each: b' is not read)
+//   x <- x + beta (v - u S v) (k_schur_step<4>, the last factor     -- 3 passes, in place in x)
+// nu launches as before, 2 nu + 2 passes instead of 3 nu (nu = 8: 18 instead of 24).  Same polynomial, other
+// arithmetic: equal to the step form to round-off (tests), not bit for bit.  `x` holds the iterate on entry
+// and the smoothed iterate on exit; va, vb are two half-vector scratch arrays.  Time-skewed order as above
+// (launch k reads what launch k-1 wrote, two rows further out; x is read by launch 0 and written by the
+// last one, whose rows lie behind everything launch 0 still has to read).
+static int schur_product_steps(sw_engine* h, Level& lv, cplx* x, cplx* va, cplx* vb, const cplx* bp, int nbp) {
+  swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
+  const int nu = (int)lv.w_eo.size();
+  const int L = lv.L;
+  cplx* buf[2] = {va, vb};
+  auto launch = [&](int k, int row0, int nrows) -> int {
+    a.row0 = row0;
+    a.nrows = nrows;
+    const int items = (nrows > 0 ? nrows : L) * (L / 2);
+    LaunchScope ls(h, T_SCHUR);
+    if (k == 0) {
+      if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
+      return launch_schur_step<1>(h, a, x, bp, buf[0], nbp);
+    }
+    const std::complex<double> u = lv.q_w[k - 1];
+    a.w = cplx{u.real(), u.imag()};
+    if (k < nu - 1) {
+      if (h->profiling) h->twork[T_SCHUR] += (double)items * (64.0 * nbp + 64.0);
+      return launch_schur_step<3>(h, a, buf[(k + 1) & 1], nullptr, buf[k & 1], nbp);
+    }
+    a.w2 = cplx{lv.q_beta.real(), lv.q_beta.imag()};
+    if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
+    return launch_schur_step<4>(h, a, buf[(k + 1) & 1], x, x, nbp);
+  };
+  const int H = skew_height(h, lv, nu, nbp);
+  if (H == 0) {
+    for (int k = 0; k < nu; ++k) SWCHK(launch(k, 0, 0));
+    return 0;
+  }
+  const int ns = L / H;
+  for (int sidx = 0; sidx < ns; ++sidx)
+    for (int k = 0; k < nu; ++k) {
+      const int row0 = (sidx == 0) ? 2 * k : sidx * H - 2 * k;
+      const int nrows = (sidx == 0) ? H - 4 * k : H;
+      SWCHK(launch(k, row0, nrows));
+    }
+  for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k));
   return 0;
 }
 
@@ -3176,6 +3250,7 @@ int sw_set_eo_smoother(sw_engine* h, int hid, int level, int n_post, const doubl
     return sw_fail(h, "level %d: the even-odd operators are not set (sw_set_eo_operator)", level);
   lv.w_eo.clear();
   for (int i = 0; i < n_post; ++i) lv.w_eo.emplace_back(w_post[2 * i], w_post[2 * i + 1]);
+  if (!swp::product_form(lv.w_eo, lv.q_w, lv.q_beta)) lv.q_w.clear();
   if (n_post > 0) lv.rich = true;     // the cycle with fixed weights (vcycle_rich)
   h->hier[hid].even_valid = false;
   return 0;
@@ -3366,6 +3441,10 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "mfma_3m") == 0) {
     h->mfma_3m = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "eo_product") == 0) {
+    h->eo_product = value != 0.0;
     return 0;
   }
   if (std::strcmp(name, "mfma3_tiles") == 0) {
@@ -3573,15 +3652,9 @@ static swk::StencilArgs eo_stencil_args(sw_engine* h, Level& lv, int nbp) {
 // Y_e = S X_e (mode 0) or Bp_e - S X_e (mode 1); all three are half vectors
 static int schur_apply(sw_engine* h, Level& lv, int mode, const cplx* X, const cplx* Bp, cplx* Y, int nbp) {
   swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
-  const int bpc = (a.Vh + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
-  const dim3 grid(bpc * (nbp / 64));
   LaunchScope ls(h, T_SCHUR_OP);
-  if (mode == 0)
-    hipLaunchKernelGGL((swk::k_schur_step<cplx, 0>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
-  else
-    hipLaunchKernelGGL((swk::k_schur_step<cplx, 1>), grid, dim3(SW_BLOCK), 0, h->stream, X, Bp, Y, a, bpc);
-  KLAUNCH_CHECK();
-  return 0;
+  if (mode == 0) return launch_schur_step<0>(h, a, X, Bp, Y, nbp);
+  return launch_schur_step<1>(h, a, X, Bp, Y, nbp);
 }
 
 static bool eo_solve_eligible(sw_engine* h, Hier& H, int level) {
@@ -3606,13 +3679,18 @@ static int vcycle_even(sw_engine* h, Hier& H, const cplx* Bin, cplx* Xout, int n
   if (!lv.Re.set) return sw_fail(h, "internal: even-column restrictor missing");
   SWCHK(launch_ell(h, lv.Re, 0, Bin, nullptr, lc.b, nbp, T_R));
   SWCHK(coarse_correction(h, H, 0, nbp));
+  // (Xout is a HALF-length array: the prolongation must write the even sites only)
+  if (!(lv.P.order_even && h->p_even))
+    return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
+  if (h->eo_product && !lv.q_w.empty() && lv.q_w.size() + 1 == lv.w_eo.size()) {
+    // product form: the coarse correction lands in Xout and is smoothed there; the two halves of lv.t are scratch
+    SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, Xout, nbp, T_P, cplx{0.0, 0.0}, true));
+    return schur_product_steps(h, lv, Xout, lv.t, lv.t + (size_t)(lv.n / 2) * nbp, Bin, nbp);
+  }
   // ping-pong between lv.t and Xout (only their even halves are touched) so that the last step lands in Xout
   const bool odd_steps = (lv.w_eo.size() & 1) != 0;
   cplx* cur = odd_steps ? lv.t : Xout;
   cplx* nxt = odd_steps ? Xout : lv.t;
-  // (Xout is a HALF-length array: the prolongation must write the even sites only)
-  if (!(lv.P.order_even && h->p_even))
-    return sw_fail(h, "internal: even-odd reduced solve needs the even-sites-only prolongation (p_even)");
   SWCHK(launch_ell(h, lv.P, 0, lc.x, nullptr, cur, nbp, T_P, cplx{0.0, 0.0}, true));
   cplx* res = nullptr;
   SWCHK(schur_steps(h, lv, cur, nxt, Bin, nbp, &res));

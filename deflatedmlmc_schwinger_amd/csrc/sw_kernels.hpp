@@ -148,6 +148,7 @@ struct StencilArgsT {
   int nbp;             // row length in elements of C
   int tile_w;          // x-extent of the lattice tiles the blocks walk (divides L)
   typename scalar_of<C>::type w;   // MODE 2 relaxation weight
+  typename scalar_of<C>::type w2 = {};   // k_schur_step MODE 4: weight of the fused update
   int nt_store;        // non-temporal output stores
   // even-odd kernels only: work on the lattice rows row0 .. row0 + nrows - 1 (mod L) instead of all of
   // them (nrows = 0): the time-skewed order of the smoother's steps on lattices beyond the Infinity Cache
@@ -367,12 +368,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_eo_hop(const C* __restrict__ Uv,
 
 // Y_e = X_e + w (Bp_e - S X_e),  S = D - H_eo H_oe / D : both hops in one kernel (even sites only)
 // MODE 2: that smoother step;  MODE 0: Y_e = S X_e;  MODE 1: Y_e = Bp_e - S X_e  (operator and residual
-// of the even-odd reduced system the outer Krylov solver works on, fgmres_eo)
+// of the even-odd reduced system the outer Krylov solver works on, fgmres_eo);
+// MODE 3: Y_e = X_e - w S X_e  (one factor of the smoother polynomial in product form: Bp is not read);
+// MODE 4: Y_e = Bp_e + w2 (X_e - w S X_e)  (the last factor, fused with the update of the iterate Bp; may run
+// in place, Y = Bp: a site reads Bp only at itself)
 template <class C, int MODE = 2>
-__global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X,
-                                                         const C* __restrict__ Bp,
-                                                         C* __restrict__ Y, StencilArgsT<C> a,
-                                                         int blocks_per_chunk) {
+__global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X, const C* Bp, C* Y,
+                                                         StencilArgsT<C> a, int blocks_per_chunk) {
   typedef SiteT<C> Site2;
   typedef typename real_of<C>::type real;
   const int bb = xcd_remap(blockIdx.x, gridDim.x);
@@ -429,13 +431,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
   const real d = a.diag, di = (real)1 / a.diag;
   const C c0 = Xc[r * nbp], c1 = Xc[(r + 1) * nbp];
   C q0 = czero<C>(), q1 = q0;
-  if (MODE != 0) {
+  if (MODE != 0 && MODE != 3) {
     q0 = Bp[r * nbp + col];
     q1 = Bp[(r + 1) * nbp + col];
   }
   // residual of S: b' - (D x - acc / D)
-  const C r0 = cschur(q0, d, c0, di, acc.s0);
-  const C r1 = cschur(q1, d, c1, di, acc.s1);
+  const C z0 = czero<C>();
+  const C r0 = cschur(MODE == 4 ? z0 : q0, d, c0, di, acc.s0);
+  const C r1 = cschur(MODE == 4 ? z0 : q1, d, c1, di, acc.s1);
   C o0, o1;
   if (MODE == 0) {          // S x = -(0 - S x)
     o0 = csub(czero<C>(), r0);
@@ -443,6 +446,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
   } else if (MODE == 1) {
     o0 = r0;
     o1 = r1;
+  } else if (MODE == 4) {
+    C v0 = c0, v1 = c1;
+    cfma(v0, a.w, r0);
+    cfma(v1, a.w, r1);
+    o0 = q0;
+    o1 = q1;
+    cfma(o0, a.w2, v0);
+    cfma(o1, a.w2, v1);
   } else {
     o0 = c0;
     o1 = c1;

@@ -196,7 +196,10 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *   stencil level: "stencil_spw", "stencil_tile", "stencil_nt" (sites per wave, lattice tile width,
  *                  non-temporal stores); "p_even" (1) prolongation onto the even sites only ahead of an
  *                  even-odd smoother; "eo_skew" (-1) time-skewed strip order of the even-odd smoother's steps
- *                  on lattices beyond the Infinity Cache (-1 automatic, 0 off, > 0 strip height in rows)
+ *                  on lattices beyond the Infinity Cache (-1 automatic, 0 off, > 0 strip height in rows);
+ *                  "eo_product" (1) the even-odd smoother of the reduced-system cycle in product form,
+ *                  x + beta prod_j (1 - u_j S)(b' - S x): the same polynomial as the steps
+ *                  x <- x + w_k (b' - S x), 2 nu + 2 half-vector passes instead of 3 nu
  *   block levels:  "use_mfma" (1) fp64-MFMA block-row kernels vs grouped ELL; "mfma_3m" (1) three real
  *                  matrix products per complex one (k_bsr_mfma3) instead of four; "mfma3_tiles" (0: by size)
  *                  tiles of 16 probes per wave in that kernel; "mfma_ops", "mfma_tiles",

@@ -396,6 +396,65 @@ def test_time_skewed_smoother_order_is_bit_identical():
         eng.close()
 
 
+def test_product_form_smoother_matches_the_step_form():
+    """engine option eo_product: the even-odd smoother of the reduced-system cycle as
+    x + beta prod_j (1 - u_j S) (b' - S x) -- the factors read one half vector and write one, 2 nu + 2 passes
+    instead of the 3 nu of the steps x <- x + w_k (b' - S x) -- against the step form: the same polynomial, so
+    the same solves to round-off (identical iteration counts, solutions equal to 1e-11, true residuals below
+    tol); plain order and time-skewed strips bit-identical to each other; 70 probes (two chunks), an even and
+    an odd number of steps; and on a 48^2 lattice (extent not a power of two) built on the device."""
+    from deflatedmlmc_schwinger_amd import hierarchy as swhier, matrix as swmatrix
+    from deflatedmlmc_schwinger_amd.multigrid import MG
+    for nu in (8, 7):
+        A, tp, mg = _tuned128(extra={"cycle": [(0, nu, 0), (0, 10, 0)]})
+        eng = mg.engine
+        n = A.shape[0]
+        B = _rand((70, n), 23 + nu)
+        out = {}
+        try:
+            for prod, H in ((0, 0), (1, 0), (1, 32), (1, 64)):
+                eng.set_option("eo_product", prod)
+                eng.set_option("eo_skew", H)
+                eng.timers_reset()
+                Xs, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+                out[(prod, H)] = (Xs, np.asarray(its), eng.launch_count())
+                true = np.linalg.norm(B.T - A @ Xs.T, axis=0) / np.linalg.norm(B.T, axis=0)
+                assert true.max() < 5e-12, (nu, prod, H, true.max())
+        finally:
+            eng.set_option("eo_skew", -1)
+            eng.set_option("eo_product", 1)
+        assert np.array_equal(out[(1, 0)][1], out[(0, 0)][1])                  # same iteration counts
+        assert out[(1, 0)][2] == out[(0, 0)][2]                                # and launches
+        assert _relerr(out[(1, 0)][0], out[(0, 0)][0]) < 1e-11
+        for H in (32, 64):
+            assert out[(1, H)][2] > out[(1, 0)][2]                             # the strips really ran
+            assert np.array_equal(out[(1, H)][0], out[(1, 0)][0]), (nu, H)
+            assert np.array_equal(out[(1, H)][1], out[(1, 0)][1]), (nu, H)
+        eng.close()
+    L = 48
+    U1, U2 = swmatrix.synthetic_links(L, 0.204, 7)
+    mg = MG((L, -0.05, U1, U2))
+    cfg = swhier.synthetic_solver_cfg(L, 4, "device")      # 4 steps: strips of 16 rows are admissible
+    mg.setup_solver_only(cfg, device=0, engines=1)
+    eng = mg.engine
+    n = 2 * L * L
+    B = _rand((64, n), 77)
+    out = {}
+    try:
+        for prod, H in ((0, 0), (1, 0), (1, 16)):
+            eng.set_option("eo_product", prod)
+            eng.set_option("eo_skew", H)
+            Xs, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+            assert np.max(rr) < 1e-12
+            out[(prod, H)] = (Xs, np.asarray(its))
+    finally:
+        eng.set_option("eo_skew", -1)
+        eng.set_option("eo_product", 1)
+    assert np.array_equal(out[(1, 0)][1], out[(0, 0)][1]) and _relerr(out[(1, 0)][0], out[(0, 0)][0]) < 1e-11
+    assert np.array_equal(out[(1, 16)][0], out[(1, 0)][0])
+    eng.close()
+
+
 def test_gram_matrix_restart_cycles_equal_the_arnoldi_ones():
     """engine option gram_cycle: the restart cycles of the even-odd reduced outer solve in Gram-matrix form
     (directions built without orthogonalisation, ONE pass for all inner products, per-probe Cholesky solve of

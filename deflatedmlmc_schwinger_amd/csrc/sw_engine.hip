@@ -209,11 +209,13 @@ struct sw_engine {
   // (strips sized for the Infinity Cache where the smoother's three half vectors exceed it), 0 off,
   // > 0 strip height in lattice rows
   int eo_skew = -1;
+  bool eo_skew_chunk = false;   // walk the strips 64-probe chunk by chunk even where the full width is admissible
   // restart cycles of the even-odd reduced outer solve in Gram-matrix form (fgmres_eo_gram)
   bool gram_cycle = true;
   // even-odd smoother of the reduced-system cycle in product form (schur_product_steps): 2 nu + 2 half-vector
   // passes instead of 3 nu
   bool eo_product = true;
+  int gj_block = 32;      // panel width of the blocked Gauss-Jordan inverse (0: unblocked)
   // levels that carry the dense inverse of their operator (sw_setup_level_inverse) are solved with it
   bool direct_small = true;
   bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
@@ -1259,20 +1261,30 @@ static int launch_schur_step(sw_engine* h, swk::StencilArgs& a, const cplx* src,
   return 0;
 }
 
-// strip height of the time-skewed order for nu launches that each reach two lattice rows (0: plain order)
-static int skew_height(sw_engine* h, Level& lv, int nu, int nbp) {
+// strip height of the time-skewed order for nu launches that each reach two lattice rows (0: plain order),
+// and the probe width the strips are walked with: all nbp probes at once where strips of at least
+// 4 (nu - 1) + 2 rows fit the cache at that width, else 64-probe chunk by chunk (the whole schedule once per
+// chunk: the same launches per probe, each a quarter as wide at nbp = 256)
+static int skew_height(sw_engine* h, Level& lv, int nu, int nbp, int* width) {
   const int L = lv.L;
-  int H = 0;
-  if (h->eo_skew != 0 && nu >= 2) {
-    const double row_bytes = (double)(L / 2) * 2.0 * sizeof(cplx) * nbp;        // one lattice row of a half vector
+  *width = nbp;
+  if (h->eo_skew == 0 || nu < 2) return 0;
+  auto admissible = [&](int H) { return H > 0 && L % H == 0 && L / H >= 2 && H > 4 * (nu - 1) && !(H & 1); };
+  for (int w = h->eo_skew_chunk ? 64 : nbp; w >= 64; w = (w > 64 ? 64 : 0)) {
+    const double row_bytes = (double)(L / 2) * 2.0 * sizeof(cplx) * w;          // one lattice row of a half vector
+    int H = 0;
     if (h->eo_skew > 0) H = h->eo_skew;
-    else if (3.0 * row_bytes * L > 208.0e6) {
+    else if (3.0 * row_bytes * L * ((double)nbp / w) > 208.0e6) {
       H = 1;
       while (2 * H <= L / 2 && 3.0 * row_bytes * (2 * H) <= 208.0e6) H *= 2;
     }
-    if (H > 0 && (L % H != 0 || L / H < 2 || H <= 4 * (nu - 1) || (H & 1))) H = 0;
+    if (admissible(H)) {
+      *width = w;
+      return H;
+    }
+    if (H == 0 || h->eo_skew > 0) break;      // nothing to skew (fits the cache), or a fixed height that is not admissible
   }
-  return H;
+  return 0;
 }
 
 // The nu Schur steps of an even-odd smoothing pass on the stencil level,
@@ -1294,6 +1306,7 @@ static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx
   swk::StencilArgs a = eo_stencil_args(h, lv, nbp);
   const int nu = (int)lv.w_eo.size();
   const int L = lv.L;
+  int c0 = 0, cw = nbp;      // probe columns of the current launches
   auto launch = [&](int k, int row0, int nrows, const cplx* src, cplx* dst) -> int {
     a.w = cplx{lv.w_eo[k].real(), lv.w_eo[k].imag()};
     a.row0 = row0;
@@ -1301,10 +1314,10 @@ static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx
     const int items = (nrows > 0 ? nrows : L) * (L / 2);
     LaunchScope ls(h, T_SCHUR);
     // algorithmic bytes: three half-vector rows per even site and spin (x_e, b'_e in, x_e out) + links
-    if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
-    return launch_schur_step<2>(h, a, src, bp, dst, nbp);
+    if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * cw + 64.0);
+    return launch_schur_step<2>(h, a, src + c0, bp + c0, dst + c0, cw);
   };
-  const int H = skew_height(h, lv, nu, nbp);      // 0 = no skewing
+  const int H = skew_height(h, lv, nu, nbp, &cw);      // 0 = no skewing
   if (H == 0) {
     for (int k = 0; k < nu; ++k) {
       SWCHK(launch(k, 0, 0, cur, nxt));
@@ -1316,13 +1329,15 @@ static int schur_steps(sw_engine* h, Level& lv, cplx* cur, cplx* nxt, const cplx
   // buf[k & 1] receives step k; step k reads buf[(k + 1) & 1] (step 0: the iterate on entry, in `cur`)
   cplx* buf[2] = {nxt, cur};
   const int ns = L / H;
-  for (int sidx = 0; sidx < ns; ++sidx)
-    for (int k = 0; k < nu; ++k) {
-      const int row0 = (sidx == 0) ? 2 * k : sidx * H - 2 * k;
-      const int nrows = (sidx == 0) ? H - 4 * k : H;
-      SWCHK(launch(k, row0, nrows, buf[(k + 1) & 1], buf[k & 1]));
-    }
-  for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k, buf[(k + 1) & 1], buf[k & 1]));
+  for (c0 = 0; c0 < nbp; c0 += cw) {
+    for (int sidx = 0; sidx < ns; ++sidx)
+      for (int k = 0; k < nu; ++k) {
+        const int row0 = (sidx == 0) ? 2 * k : sidx * H - 2 * k;
+        const int nrows = (sidx == 0) ? H - 4 * k : H;
+        SWCHK(launch(k, row0, nrows, buf[(k + 1) & 1], buf[k & 1]));
+      }
+    for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k, buf[(k + 1) & 1], buf[k & 1]));
+  }
   *result = buf[(nu - 1) & 1];
   return 0;
 }
@@ -1343,38 +1358,41 @@ static int schur_product_steps(sw_engine* h, Level& lv, cplx* x, cplx* va, cplx*
   const int nu = (int)lv.w_eo.size();
   const int L = lv.L;
   cplx* buf[2] = {va, vb};
+  int c0 = 0, cw = nbp;      // probe columns of the current launches
   auto launch = [&](int k, int row0, int nrows) -> int {
     a.row0 = row0;
     a.nrows = nrows;
     const int items = (nrows > 0 ? nrows : L) * (L / 2);
     LaunchScope ls(h, T_SCHUR);
     if (k == 0) {
-      if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
-      return launch_schur_step<1>(h, a, x, bp, buf[0], nbp);
+      if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * cw + 64.0);
+      return launch_schur_step<1>(h, a, x + c0, bp + c0, buf[0] + c0, cw);
     }
     const std::complex<double> u = lv.q_w[k - 1];
     a.w = cplx{u.real(), u.imag()};
     if (k < nu - 1) {
-      if (h->profiling) h->twork[T_SCHUR] += (double)items * (64.0 * nbp + 64.0);
-      return launch_schur_step<3>(h, a, buf[(k + 1) & 1], nullptr, buf[k & 1], nbp);
+      if (h->profiling) h->twork[T_SCHUR] += (double)items * (64.0 * cw + 64.0);
+      return launch_schur_step<3>(h, a, buf[(k + 1) & 1] + c0, nullptr, buf[k & 1] + c0, cw);
     }
     a.w2 = cplx{lv.q_beta.real(), lv.q_beta.imag()};
-    if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * nbp + 64.0);
-    return launch_schur_step<4>(h, a, buf[(k + 1) & 1], x, x, nbp);
+    if (h->profiling) h->twork[T_SCHUR] += (double)items * (96.0 * cw + 64.0);
+    return launch_schur_step<4>(h, a, buf[(k + 1) & 1] + c0, x + c0, x + c0, cw);
   };
-  const int H = skew_height(h, lv, nu, nbp);
+  const int H = skew_height(h, lv, nu, nbp, &cw);
   if (H == 0) {
     for (int k = 0; k < nu; ++k) SWCHK(launch(k, 0, 0));
     return 0;
   }
   const int ns = L / H;
-  for (int sidx = 0; sidx < ns; ++sidx)
-    for (int k = 0; k < nu; ++k) {
-      const int row0 = (sidx == 0) ? 2 * k : sidx * H - 2 * k;
-      const int nrows = (sidx == 0) ? H - 4 * k : H;
-      SWCHK(launch(k, row0, nrows));
-    }
-  for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k));
+  for (c0 = 0; c0 < nbp; c0 += cw) {
+    for (int sidx = 0; sidx < ns; ++sidx)
+      for (int k = 0; k < nu; ++k) {
+        const int row0 = (sidx == 0) ? 2 * k : sidx * H - 2 * k;
+        const int nrows = (sidx == 0) ? H - 4 * k : H;
+        SWCHK(launch(k, row0, nrows));
+      }
+    for (int k = 1; k < nu; ++k) SWCHK(launch(k, L - 2 * k, 4 * k));
+  }
   return 0;
 }
 
@@ -2638,6 +2656,12 @@ int sw_setup_galerkin(sw_engine* h, int hid, int level, int Lc, const int32_t* n
 // In-place inverse of the dense row-major n x n matrix D on the device: Gauss-Jordan with partial
 // pivoting (the device counterpart of np.linalg.inv at multigrid.py:342-344); hand-written kernels, no
 // library handle involved.  Four small launches per pivot step.
+// In-place inverse of the dense row-major [n][n] matrix D: Gauss-Jordan with partial pivoting.  Blocked
+// (option gj_block, default 32 columns; n a multiple of 64): the pivot steps of a panel update the panel
+// only (n x nb), after which the panel is N = G E -- the panel's composite transformation applied to the unit
+// columns -- and every other column c becomes a[:, c] (pivot rows zeroed) + N a[pivot rows, c]: one rank-nb
+// update on the fp64 matrix cores (k_bsr_mfma3 in residual mode on the negated panel, the matrix as nbp = n
+// "probes").  n = 4096: 0.355 s -> see profiles/r03_ab_sessions.txt (r03ab).
 static int gj_invert(sw_engine* h, cplx* D, int n) {
   cplx* colk = nullptr;
   cplx* pvinv = nullptr;
@@ -2647,25 +2671,65 @@ static int gj_invert(sw_engine* h, cplx* D, int n) {
   SWCHK(dev_realloc(h, &pivs, (size_t)n + 1));
   int* info = pivs + n;
   HIPCHK(hipMemsetAsync(info, 0, sizeof(int), h->stream));
-  {
-    const dim3 g1((n + SW_BLOCK - 1) / SW_BLOCK);
-    const dim3 gu((n + 63) / 64, (n + 16 * SW_WAVES_PER_BLOCK - 1) / (16 * SW_WAVES_PER_BLOCK));
+  const int nb = (h->gj_block >= 8 && h->gj_block % 8 == 0 && n % 64 == 0 && n % h->gj_block == 0 &&
+                  n >= 4 * h->gj_block && h->use_mfma && h->mfma_3m) ? h->gj_block : 0;
+  const dim3 g1((n + SW_BLOCK - 1) / SW_BLOCK);
+  auto pivot_step = [&](int k, int c0, int cn) {
+    const dim3 gu((cn + 63) / 64, (n + 16 * SW_WAVES_PER_BLOCK - 1) / (16 * SW_WAVES_PER_BLOCK));
+    hipLaunchKernelGGL(swk::k_gj_pivot, dim3(1), dim3(1024), 0, h->stream, (const cplx*)D, n, k, pivs, pvinv,
+                       info);
+    hipLaunchKernelGGL(swk::k_gj_swap_rows, dim3((cn + SW_BLOCK - 1) / SW_BLOCK), dim3(SW_BLOCK), 0, h->stream, D,
+                       n, k, (const int*)pivs, c0, cn);
+    hipLaunchKernelGGL(swk::k_gj_column_and_scale, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k,
+                       (const cplx*)pvinv, colk, c0, cn);
+    hipLaunchKernelGGL(swk::k_gj_update, gu, dim3(SW_BLOCK), 0, h->stream, D, n, k, (const cplx*)colk, c0, cn);
+    h->launches += 4;
+  };
+  if (nb == 0) {
     for (int k = 0; k < n; ++k) {
-      hipLaunchKernelGGL(swk::k_gj_pivot, dim3(1), dim3(1024), 0, h->stream, (const cplx*)D, n, k, pivs,
-                         pvinv, info);
-      hipLaunchKernelGGL(swk::k_gj_swap_rows, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k, (const int*)pivs);
-      hipLaunchKernelGGL(swk::k_gj_column_and_scale, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k,
-                         (const cplx*)pvinv, colk);
-      hipLaunchKernelGGL(swk::k_gj_update, gu, dim3(SW_BLOCK), 0, h->stream, D, n, k, (const cplx*)colk);
+      pivot_step(k, 0, n);
       // keep the queue shallow: thousands of back-to-back launches without a host sync overran
       // rocprofv3's per-dispatch counter buffers (FETCH_SIZE pass, n = 2048: segmentation fault inside
       // the tool); a drain every 256 pivot steps costs nothing measurable
       if ((k & 255) == 255) HIPCHK(hipStreamSynchronize(h->stream));
     }
-    hipLaunchKernelGGL(swk::k_gj_unpermute, g1, dim3(SW_BLOCK), 0, h->stream, D, n, (const int*)pivs);
-    KLAUNCH_CHECK();
-    h->launches += 4 * (long long)n + 1;
+  } else {
+    cplx* T = nullptr;
+    EllOp pn;                       // -N of the current panel in block-row form
+    pn.nrows = n;
+    pn.ncols = nb;
+    pn.bsr_KS = nb / 4;
+    pn.set = true;
+    SWCHK(dev_realloc(h, &T, (size_t)nb * n));
+    SWCHK(dev_realloc(h, &pn.bsr_vals, (size_t)(n / 16) * pn.bsr_KS * 64));
+    SWCHK(dev_realloc(h, &pn.bsr_kcol, (size_t)(n / 16) * pn.bsr_KS));
+    const size_t items = (size_t)(n / 16) * pn.bsr_KS;
+    for (int k0 = 0; k0 < n; k0 += nb) {
+      if (nb <= 64) {
+        for (int k = k0; k < k0 + nb; ++k) {
+          hipLaunchKernelGGL(swk::k_gj_pivot_panel, dim3(1), dim3(1024), 0, h->stream, D, n, k, k0, nb, pivs, info);
+          hipLaunchKernelGGL(swk::k_gj_update_panel, dim3((n + 16 * SW_WAVES_PER_BLOCK - 1) / (16 * SW_WAVES_PER_BLOCK)),
+                             dim3(SW_BLOCK), 0, h->stream, D, n, k, k0, nb);
+        }
+        h->launches += 2 * nb;
+      } else {
+        for (int k = k0; k < k0 + nb; ++k) pivot_step(k, k0, nb);
+      }
+      hipLaunchKernelGGL(swk::k_gj_block_rows, g1, dim3(SW_BLOCK), 0, h->stream, D, n, k0, nb, (const int*)pivs, T);
+      hipLaunchKernelGGL(swk::k_gj_panel_to_bsr, dim3((unsigned)((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK)),
+                         dim3(SW_BLOCK), 0, h->stream, (const cplx*)D, n, k0, nb, pn.bsr_vals, pn.bsr_kcol);
+      KLAUNCH_CHECK();
+      h->launches += 2;
+      SWCHK(launch_bsr(h, pn, 1, T, D, D, n, T_OTHER, cplx{0.0, 0.0}));
+      if (((k0 / nb) & 7) == 7) HIPCHK(hipStreamSynchronize(h->stream));      // (shallow queue, as above)
+    }
+    SWCHK(stream_sync(h));
+    SWCHK(dev_free(h, T));
+    SWCHK(free_op(h, pn));
   }
+  hipLaunchKernelGGL(swk::k_gj_unpermute, g1, dim3(SW_BLOCK), 0, h->stream, D, n, (const int*)pivs);
+  KLAUNCH_CHECK();
+  h->launches += 1;
   int hinfo = 0;
   HIPCHK(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   SWCHK(stream_sync(h));
@@ -3441,6 +3505,16 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   }
   if (std::strcmp(name, "mfma_3m") == 0) {
     h->mfma_3m = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "eo_skew_chunk") == 0) {
+    h->eo_skew_chunk = value != 0.0;
+    return 0;
+  }
+  if (std::strcmp(name, "gj_block") == 0) {
+    const int v = (int)value;
+    if (v != 0 && (v < 8 || v > 256 || v % 8)) return sw_fail(h, "gj_block must be 0 or a multiple of 8 in 8..256");
+    h->gj_block = v;
     return 0;
   }
   if (std::strcmp(name, "eo_product") == 0) {

@@ -1107,9 +1107,11 @@ __global__ __launch_bounds__(256) void k_block_products(const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// In-place dense inverse of the coarsest operator (sw_setup_invert_coarsest): Gauss-Jordan with
-// partial pivoting on the row-major [n][n] matrix, four small launches per pivot step (n <= 8192:
-// the whole inverse is n^3 complex updates = 0.2 s of HBM traffic at n = 4096, 3 ms at n = 1024).
+// In-place dense inverse (gj_invert: coarsest operator, directly solved levels): Gauss-Jordan with
+// partial pivoting on the row-major [n][n] matrix, four small launches per pivot step.  Unblocked, every
+// step is a rank-1 update of the whole matrix (n^3 complex updates = 0.35 s of memory traffic at n = 4096);
+// blocked, the steps of a panel of nb columns touch the panel only and the rest of the matrix follows in one
+// rank-nb update on the matrix cores (k_gj_block_rows, k_gj_panel_to_bsr, k_bsr_mfma3).
 //   step k:  p = argmax_{r >= k} |a[r][k]| ;  rows k <-> p ;  c_r = a[r][k], column k := e_k ;
 //            row k *= 1 / pivot ;  a[r][:] -= c_r a[k][:]  (r != k) ;   afterwards the row swaps are
 //   undone on the columns in reverse order.
@@ -1154,33 +1156,42 @@ __global__ __launch_bounds__(1024) void k_gj_pivot(const cplx* __restrict__ A, i
   }
 }
 
+// (the three row kernels work on the column window [c0, c0 + cn): the whole matrix in the unblocked
+// algorithm, the current panel in the blocked one)
 __global__ __launch_bounds__(SW_BLOCK) void k_gj_swap_rows(cplx* __restrict__ A, int n, int k,
-                                                           const int* __restrict__ pivs) {
-  const int c = blockIdx.x * SW_BLOCK + threadIdx.x;
+                                                           const int* __restrict__ pivs, int c0, int cn) {
+  const int t = blockIdx.x * SW_BLOCK + threadIdx.x;
   const int p = pivs[k];
-  if (c >= n || p == k) return;
-  const cplx t = A[(size_t)k * n + c];
+  if (t >= cn || p == k) return;
+  const int c = c0 + t;
+  const cplx v = A[(size_t)k * n + c];
   A[(size_t)k * n + c] = A[(size_t)p * n + c];
-  A[(size_t)p * n + c] = t;
+  A[(size_t)p * n + c] = v;
 }
 
-// thread t: as a row, colk[t] = a[t][k] and a[t][k] := (t == k); then, as a column, a[k][t] *= 1/pivot
+// thread t: as a row, colk[t] = a[t][k] and a[t][k] := 0 (t != k); then, as a column of the window,
+// a[k][c0 + t] *= 1/pivot, where a[k][k] counts as 1 (column k := e_k)
 __global__ __launch_bounds__(SW_BLOCK) void k_gj_column_and_scale(cplx* __restrict__ A, int n, int k,
                                                                   const cplx* __restrict__ pvinv,
-                                                                  cplx* __restrict__ colk) {
+                                                                  cplx* __restrict__ colk, int c0, int cn) {
   const int t = blockIdx.x * SW_BLOCK + threadIdx.x;
-  if (t >= n) return;
-  colk[t] = A[(size_t)t * n + k];
-  A[(size_t)t * n + k] = cmake(t == k ? 1.0 : 0.0, 0.0);
-  A[(size_t)k * n + t] = cmul(A[(size_t)k * n + t], *pvinv);
+  if (t < n && t != k) {
+    colk[t] = A[(size_t)t * n + k];
+    A[(size_t)t * n + k] = cmake(0.0, 0.0);
+  }
+  if (t < cn) {
+    const int c = c0 + t;
+    A[(size_t)k * n + c] = (c == k) ? *pvinv : cmul(A[(size_t)k * n + c], *pvinv);
+  }
 }
 
-// a[r][c] -= colk[r] * a[k][c] for r != k; one wave per row segment of 64 columns
+// a[r][c] -= colk[r] * a[k][c] for r != k, c in the window; one wave per row segment of 64 columns
 __global__ __launch_bounds__(SW_BLOCK) void k_gj_update(cplx* __restrict__ A, int n, int k,
-                                                        const cplx* __restrict__ colk) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+                                                        const cplx* __restrict__ colk, int c0, int cn) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
   const int r0 = (blockIdx.y * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
-  if (c >= n) return;
+  if (t >= cn) return;
+  const int c = c0 + t;
   const cplx rk = A[(size_t)k * n + c];
 #pragma unroll 4
   for (int r = r0; r < r0 + 16 && r < n; ++r) {
@@ -1190,6 +1201,110 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gj_update(cplx* __restrict__ A, in
     cfma(v, cmake(-f.x, -f.y), rk);
     A[(size_t)r * n + c] = v;
   }
+}
+
+// The pivot step of the blocked algorithm in two launches (panel of at most 64 columns).
+// k_gj_pivot_panel, one workgroup: p = argmax_{r >= k} |a[r][k]|; rows k <-> p inside the panel; row k of
+// the panel *= 1 / pivot, with a[k][k] := 1 / pivot.
+__global__ __launch_bounds__(1024) void k_gj_pivot_panel(cplx* __restrict__ A, int n, int k, int c0, int cn,
+                                                         int* __restrict__ pivs, int* __restrict__ info) {
+  __shared__ double bm[1024];
+  __shared__ int bi[1024];
+  const int t = threadIdx.x;
+  double best = -1.0;
+  int arg = k;
+  for (int r = k + t; r < n; r += 1024) {
+    const cplx v = A[(size_t)r * n + k];
+    const double m = v.x * v.x + v.y * v.y;
+    if (m > best) {
+      best = m;
+      arg = r;
+    }
+  }
+  bm[t] = best;
+  bi[t] = arg;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (t < s && (bm[t + s] > bm[t] || (bm[t + s] == bm[t] && bi[t + s] < bi[t]))) {
+      bm[t] = bm[t + s];
+      bi[t] = bi[t + s];
+    }
+    __syncthreads();
+  }
+  const int p = bi[0];
+  const cplx pv = A[(size_t)p * n + k];
+  const double d = pv.x * pv.x + pv.y * pv.y;
+  const cplx pinv = d > 0.0 ? cmake(pv.x / d, -pv.y / d) : cmake(0.0, 0.0);
+  __syncthreads();                       // every thread has read the pivot before the rows move
+  if (t == 0) {
+    pivs[k] = p;
+    if (!(d > 0.0)) atomicOr(info, 1);
+  }
+  if (t < cn) {
+    const int c = c0 + t;
+    const cplx vp = A[(size_t)p * n + c];
+    if (p != k) A[(size_t)p * n + c] = A[(size_t)k * n + c];
+    A[(size_t)k * n + c] = (c == k) ? pinv : cmul(vp, pinv);
+  }
+}
+
+// k_gj_update_panel: a[r][c] -= a[r][k] a[k][c] for r != k and the panel's columns c != k, a[r][k] := -a[r][k] a[k][k]
+// (column k := e_k before the update).  One wave = 16 rows x the panel (cn <= 64: one lane per column, so the
+// lanes of a wave read a[r][k] before the lane of column k overwrites it).
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_update_panel(cplx* __restrict__ A, int n, int k, int c0, int cn) {
+  const int t = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
+  const int c = c0 + (t < cn ? t : 0);
+  const cplx rk = A[(size_t)k * n + c];
+#pragma unroll 4
+  for (int r = r0; r < r0 + 16 && r < n; ++r) {
+    if (r == k) continue;
+    const cplx f = A[(size_t)r * n + k];
+    cplx v = (c == k) ? cmake(0.0, 0.0) : A[(size_t)r * n + c];
+    cfma(v, cmake(-f.x, -f.y), rk);
+    if (t < cn) A[(size_t)r * n + c] = v;
+  }
+}
+
+// Blocked Gauss-Jordan (gj_invert): after the nb columns k0 .. k0 + nb - 1 have been eliminated inside their
+// panel, the panel holds N = G E (the composite transformation applied to the unit columns), and the other
+// columns c follow as  a[:, c] <- a[:, c] with the pivot rows zeroed  +  N a[k0 .. k0 + nb, c].
+// k_gj_block_rows, one thread per column: the panel's nb row swaps, then T[b][c] = a[k0 + b][c] and
+// a[k0 + b][c] := 0 (columns of the panel: T = 0, nothing else).
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_block_rows(cplx* __restrict__ A, int n, int k0, int nb,
+                                                            const int* __restrict__ pivs, cplx* __restrict__ T) {
+  const int c = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (c >= n) return;
+  if (c >= k0 && c < k0 + nb) {
+    for (int b = 0; b < nb; ++b) T[(size_t)b * n + c] = cmake(0.0, 0.0);
+    return;
+  }
+  for (int j = k0; j < k0 + nb; ++j) {
+    const int p = pivs[j];
+    if (p != j) {
+      const cplx v = A[(size_t)j * n + c];
+      A[(size_t)j * n + c] = A[(size_t)p * n + c];
+      A[(size_t)p * n + c] = v;
+    }
+  }
+  for (int b = 0; b < nb; ++b) {
+    T[(size_t)b * n + c] = A[(size_t)(k0 + b) * n + c];
+    A[(size_t)(k0 + b) * n + c] = cmake(0.0, 0.0);
+  }
+}
+
+// -N, the negated panel a[:, k0 .. k0 + nb), in MFMA block-row form (KS = nb / 4 four-column groups per
+// 16-row tile, k_dense_to_bsr's tile layout), so that k_bsr_mfma3's residual mode does a <- a - (-N) T
+__global__ __launch_bounds__(SW_BLOCK) void k_gj_panel_to_bsr(const cplx* __restrict__ A, int n, int k0, int nb,
+                                                              cplx* __restrict__ vals, int* __restrict__ kcol) {
+  const int lane = threadIdx.x & 63;
+  const int KS = nb >> 2;
+  const size_t item = (size_t)blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= (size_t)(n >> 4) * KS) return;
+  const int rt = (int)(item / KS), ks = (int)(item - (size_t)rt * KS);
+  const cplx v = A[((size_t)rt * 16 + (lane & 15)) * n + k0 + 4 * ks + (lane >> 4)];
+  vals[item * 64 + lane] = cmake(-v.x, -v.y);
+  if (lane == 0) kcol[item] = 4 * ks;
 }
 
 // undo the row swaps on the columns, last swap first; one thread per row

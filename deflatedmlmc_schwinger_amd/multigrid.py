@@ -5,6 +5,7 @@ behind ``matvec`` / ``one_mg_step`` / ``solve`` / ``diff_op`` runs in the HIP li
 :mod:`deflatedmlmc_schwinger_amd.engine`.  Setup (ARPACK test vectors, Galerkin products,
 dense inverse) stays on the host exactly as in the reference and is uploaded once.
 """
+import os
 import time
 
 import numpy as np
@@ -39,6 +40,15 @@ def collective_reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params,
         built = _hier.reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params,
                                           testvectors=tv)
     return built
+
+
+def _new_engine(device):
+    """An engine with the switches of SW_ENGINE_OPTS (comma-separated name=value, as bench.py's --engine-opts)
+    set before anything is built: A/B runs of switches that act during the setup (e.g. gj_block)."""
+    eng = Engine(device)
+    for kv in [x for x in os.environ.get("SW_ENGINE_OPTS", "").split(",") if x]:
+        eng.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+    return eng
 
 
 class MG:
@@ -114,7 +124,7 @@ class MG:
         self.ml = SimpleML()
         self.ml.levels.append(lev)
         self.total_levels = 1
-        self.engines = [Engine(device) for _ in range(max(1, engines))]
+        self.engines = [_new_engine(device) for _ in range(max(1, engines))]
         self.engine = self.engines[0]
         for eng in self.engines:
             eng.hier_begin(REF_HID, 1)
@@ -134,7 +144,7 @@ class MG:
         device = int(params.get("device", self.device)) if params else self.device
         nr_engines = max(1, int(params.get("engines", 1))) if params else 1
         if self.engine is None:
-            self.engines = [Engine(device) for _ in range(nr_engines)]
+            self.engines = [_new_engine(device) for _ in range(nr_engines)]
             self.engine = self.engines[0]
         levels = self.ml.levels
         nlev = len(levels)

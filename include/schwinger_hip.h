@@ -196,7 +196,9 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *   stencil level: "stencil_spw", "stencil_tile", "stencil_nt" (sites per wave, lattice tile width,
  *                  non-temporal stores); "p_even" (1) prolongation onto the even sites only ahead of an
  *                  even-odd smoother; "eo_skew" (-1) time-skewed strip order of the even-odd smoother's steps
- *                  on lattices beyond the Infinity Cache (-1 automatic, 0 off, > 0 strip height in rows);
+ *                  on lattices beyond the Infinity Cache (-1 automatic, 0 off, > 0 strip height in rows; batches
+ *                  too wide for admissible strips are walked 64-probe chunk by chunk, "eo_skew_chunk" (0)
+ *                  forces that);
  *                  "eo_product" (1) the even-odd smoother of the reduced-system cycle in product form,
  *                  x + beta prod_j (1 - u_j S)(b' - S x): the same polynomial as the steps
  *                  x <- x + w_k (b' - S x), 2 nu + 2 half-vector passes instead of 3 nu
@@ -206,6 +208,7 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *                  "mfma_small_tiles", "bsr_stages" / "dense_stages" (register pipeline depth), "bsr_nt",
  *                  "bsr_xreg", "bsr_sub", "dense_map", "ell_order"; complex64 twins "f32_tiles",
  *                  "f32_stages", "f32_dense_stages", "f32_splitk", "f32_pairs"
+ *   setup:         "gj_block" (32) panel width of the blocked Gauss-Jordan inverse (0: unblocked)
  *   sw_bench_dirac: "bench_mode" (0 Y=AX, 1 residual, 2 smoother step), "bench_what" (operator / R / P /
  *                  coarsest) */
 int sw_set_option(sw_engine* h, const char* name, double value);

@@ -321,6 +321,43 @@ def test_dense_schur_inverse_built_on_the_device_matches_the_host_route():
     assert np.abs(np.delete(res["device"], E, axis=1)).max() == 0.0          # odd rows untouched
 
 
+def test_blocked_gauss_jordan_inverse_matches_the_unblocked_one():
+    """engine option gj_block: the device-side dense inverse with the pivot steps of a 32-column panel
+    confined to the panel and the rest of the matrix updated once per panel on the matrix cores, against the
+    unblocked algorithm (a rank-1 update of the whole matrix per pivot step): the 1024-row coarsest operator
+    of the tuned hierarchy and the 2048-row Schur complement of its 4096-row level, panels of 32 and 64
+    columns -- both inverses applied through the C ABI, compared with each other and checked as inverses
+    (S S^-1 = 1; A_c A_c^-1 = 1 through the level's block-row operator)."""
+    A, tp, mg = _tuned128(extra={"direct_levels": [1]})
+    eng = mg.engine
+    nc = mg.solver_info["levels"][-1]
+    last = len(mg.solver_info["levels"]) - 1
+    Lc = 16
+    site = np.arange(Lc * Lc)
+    even = (((site % Lc) + (site // Lc)) & 1) == 0
+    E = np.nonzero(np.repeat(even, 16))[0]
+    Xs = np.zeros((5, Lc * Lc * 16), dtype=complex)
+    Xs[:, E] = _rand((5, E.size), 81)
+    Xc = _rand((5, nc), 82)
+    out = {}
+    try:
+        for blk in (0, 32, 64):
+            eng.set_option("gj_block", blk)
+            eng.setup_invert_coarsest(SOLVER_HID)
+            eng.setup_direct_level(SOLVER_HID, 1)
+            Yc = eng.coarsest(SOLVER_HID, Xc)
+            Ys = eng.apply_eo_operator(SOLVER_HID, 1, 4, Xs)
+            assert _relerr(eng.apply_dirac(SOLVER_HID, last, Yc), Xc) < 1e-11, blk
+            assert _relerr(eng.apply_eo_operator(SOLVER_HID, 1, 0, Ys)[:, E], Xs[:, E]) < 1e-11, blk
+            out[blk] = (Yc, Ys)
+    finally:
+        eng.set_option("gj_block", 32)
+    for blk in (32, 64):
+        assert _relerr(out[blk][0], out[0][0]) < 1e-11
+        assert _relerr(out[blk][1], out[0][1]) < 1e-11
+    eng.close()
+
+
 def test_three_product_block_row_kernel_matches_the_four_product_one():
     """engine option mfma_3m: the block-row operator with three real matrix products per complex one
     (k_bsr_mfma3: T1 = Ar Xr, T2 = Ai Xi, T3 = (Ar + Ai)(Xr + Xi)) against the four-product kernel and
@@ -379,8 +416,9 @@ def test_time_skewed_smoother_order_is_bit_identical():
         B = _rand((70, n), 19 + nu)
         ref = None
         try:
-            for H in (0, 32, 64):
+            for H, chunked in ((0, 0), (32, 0), (64, 0), (32, 1)):
                 eng.set_option("eo_skew", H)
+                eng.set_option("eo_skew_chunk", chunked)      # strips walked 64-probe chunk by chunk
                 eng.timers_reset()
                 Xc = eng.vcycle(SOLVER_HID, 0, B)                           # full-system cycle (eo_smooth)
                 launches = eng.launch_count()
@@ -393,6 +431,7 @@ def test_time_skewed_smoother_order_is_bit_identical():
                 assert np.array_equal(Xs, ref[1]) and np.array_equal(np.asarray(its), ref[2]), (nu, H)
         finally:
             eng.set_option("eo_skew", -1)
+            eng.set_option("eo_skew_chunk", 0)
         eng.close()
 
 

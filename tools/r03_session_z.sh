@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 3: sliding-window Schur kernel (eo_tab) against k_schur_step: bit identity, then A/B of the bench
+# (the eo_tab option and its kernel were removed after this session: profiles/r03_ab_sessions.txt, r03z)
 OUT=gpurun_out/${1:-r03z}
 mkdir -p $OUT
 export OMP_NUM_THREADS=1

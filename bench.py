@@ -650,8 +650,9 @@ def other_configs(args, mg, n, device_index):
         mg5, _, _, _, n5, ts = build_problem("synthetic", a5, device_index, 1)
         try:
             r = secondary("BASELINE config 5's lattice: synthetic 1024^2 random U(1) gauge field (sigma 0.204, "
-                          "m -0.05), 64 plain Hutchinson probes per batch, five-level hierarchy built on the GPU",
-                          mg5, MODE_HUTCHINSON, 64, n5, args.tol, 2, 1)
+                          "m -0.05), 128 plain Hutchinson probes per batch (64: 4 % less, profiles/"
+                          "r03_ab_sessions.txt r03aa), five-level hierarchy built on the GPU",
+                          mg5, MODE_HUTCHINSON, 128, n5, args.tol, 2, 1)
             r["setup_s"] = ts
             r["setup_log"] = (mg5.solver_info or {}).get("setup_log")
             return r

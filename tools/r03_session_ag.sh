@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 3: k_schur_step with a capped grid whose workgroups walk the sites (schur_grid) against one workgroup per
+# (the schur_grid option was removed after this session: profiles/r03_ab_sessions.txt, r03ag)
 # four sites
 OUT=gpurun_out/${1:-r03ag}
 mkdir -p $OUT

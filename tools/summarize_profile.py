@@ -86,6 +86,24 @@ def main(out, extra=""):
                     summary[tag] = {"hbm_bytes_per_launch": (fmb + wmb) * 1e6,
                                     "fetch_bytes_per_launch_corrected": fmb * 1e6,
                                     "write_bytes_per_launch": wmb * 1e6}
+    # the even-odd smoother class of bench.py ("k_schur_step") in product form: launch-weighted mean over its
+    # factor launches <3>, the fused last factors <4> and one residual <1> per smoothing pass (= per <4>)
+    def _mb(counter, key, scale):
+        v = pmc.get(counter, {}).get(key)
+        return (scale * v[1] / v[0] * 1024 / 1e6, v[0]) if v else None
+    k3, k4, k1 = ("swk::k_schur_step<cplx, %d>" % m for m in (3, 4, 1))
+    if pmc and all(_mb("FETCH_SIZE", k, 2.0) and _mb("WRITE_SIZE", k, 1.0) for k in (k3, k4, k1)):
+        n3, n4 = _mb("FETCH_SIZE", k3, 2.0)[1], _mb("FETCH_SIZE", k4, 2.0)[1]
+        wts = {k3: n3, k4: n4, k1: n4}
+        tot = float(sum(wts.values()))
+        fmb = sum(_mb("FETCH_SIZE", k, 2.0)[0] * w for k, w in wts.items()) / tot
+        wmb = sum(_mb("WRITE_SIZE", k, 1.0)[0] * w for k, w in wts.items()) / tot
+        summary["k_schur_step"] = {"hbm_bytes_per_launch": (fmb + wmb) * 1e6,
+                                   "fetch_bytes_per_launch_corrected": fmb * 1e6,
+                                   "write_bytes_per_launch": wmb * 1e6,
+                                   "composition": "product form: %d launches <3>, %d <4>, %d <1>" % (n3, n4, n4)}
+        lines.append("%-72s %12.2f %12.2f %12.2f" % ("class k_schur_step (smoother, product form: <3>, <4>, <1>)",
+                                                     fmb, wmb, fmb + wmb))
     # hierarchies whose first block level is small run it on the NT = 2 variant: bench.py calls the
     # first block level "level-1 operator" whatever its size
     l1, l2 = "k_bsr_mfma(level-1 operator)", "k_bsr_mfma(level-2 operator)"

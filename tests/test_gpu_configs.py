@@ -81,6 +81,38 @@ def test_config5_full_size_synthetic_1024_lattice():
     eng.close()
 
 
+def test_wide_batch_on_the_512_lattice_walks_the_strips_chunk_by_chunk():
+    """A 128-probe batch on the synthetic 512^2 lattice: strips of the full batch width that fit the cache
+    would be 32 lattice rows, fewer than the 10 smoother launches reach (36), so the time-skewed schedule is
+    walked once per 64-probe chunk with strips of 64 rows (skew_height).  The solutions must be bit-identical
+    to the plain order's, and their TRUE residuals, recomputed on the host with the CSR operator, below 5e-12."""
+    L, mass, nb = 512, -0.05, 128
+    U1, U2 = matrix.synthetic_links(L, 0.204, 2024)
+    mg = MG((L, mass, U1, U2))
+    mg.setup_solver_only(hierarchy.synthetic_solver_cfg(L), device=0, engines=1)
+    eng = mg.engine
+    n = 2 * L * L
+    B = _rand((nb, n), 512)
+    out = {}
+    try:
+        for H in (-1, 0):
+            eng.set_option("eo_skew", H)
+            eng.timers_reset()
+            X, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 1000)
+            out[H] = (X, np.asarray(its), eng.launch_count())
+    finally:
+        eng.set_option("eo_skew", -1)
+    assert out[-1][2] > out[0][2]                                   # the strips really ran
+    assert np.array_equal(out[-1][0], out[0][0]) and np.array_equal(out[-1][1], out[0][1])
+    A = (hierarchy.wilson_from_links(U1, U2, L) + mass * sp.identity(n, dtype=np.complex128, format="csr")).tocsr()
+    worst = 0.0
+    for k0 in range(0, nb, 16):
+        R = B[k0:k0 + 16].T - A @ out[-1][0][k0:k0 + 16].T
+        worst = max(worst, float(np.max(np.linalg.norm(R, axis=0) / np.linalg.norm(B[k0:k0 + 16].T, axis=0))))
+    assert worst < 5e-12, worst
+    eng.close()
+
+
 def test_config3_as_written_two_level_mlmc_difference():
     """BASELINE config 3 literally: schwinger128, a 2-level hierarchy 32768 -> 8192 (the
     reference's aggregation), the MLMC difference probe e = x^H A_0^-1 C x - x^H P A_c^-1 R C x with the

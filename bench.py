@@ -167,12 +167,15 @@ def build_problem(workload, args, device_index, engines):
         params['max_nr_levels'] = 2
         params['nr_deflat_vctrs'] = 0
         params['use_solver_hierarchy'] = False
-        # smoother of the lattice level: a degree-64 polynomial on its even-odd Schur complement (half vectors,
-        # outer solve on the reduced system): 4.1k probe-samples/s at 12 iterations against 1.6k at 22 with the
-        # degree-48 polynomial on the full operator (profiles/r03_ab_sessions.txt, r03s)
+        # smoother of the lattice level: a degree-48 polynomial on its even-odd Schur complement (half vectors,
+        # product form, outer solve on the reduced system): 14 iterations against 22 with a degree-48
+        # polynomial on the full operator (profiles/r03_ab_sessions.txt, r03s, r03aj)
         params['ref_smoother'] = os.environ.get("SW_CONFIG2_SMOOTHER", "eo")
-        params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "64"))
+        params['ref_cycle_post'] = int(os.environ.get("SW_CONFIG2_NU", "48"))
         params['solver_restart'] = int(os.environ.get("SW_CONFIG2_RESTART", "16"))
+        # the 8192-row coarse level solved exactly in even-odd form (dense 4096^2 inverse of the Schur
+        # complement of its 16-row tiles + three sparse block operators) instead of the dense 8192^2 inverse
+        params['ref_coarsest'] = os.environ.get("SW_CONFIG2_COARSEST", "eo")
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
     tp = utils.trace_params_from_params(params, "mlmc" if workload == "mlmc" else "hutchinson")
     mg = MG(A)
@@ -572,9 +575,11 @@ def run(args):
                             "BASELINE config 2 as written: schwinger128, %d x %d probes/GPU/step as "
                             "multi-RHS batches, plain Hutchinson (k=0, Pperm shift 512), 2-level "
                             "multigrid 32768 -> 8192 (reference aggregation: 32-row aggregates, 4 test "
-                            "vectors x 2; dense 8192^2 coarse inverse on fp64 MFMA; lattice-level smoother %s "
+                            "vectors x 2; coarse level solved exactly on fp64 MFMA, %s; lattice-level smoother %s "
                             "degree %d), fp64, tol %.0e"
-                            % (ne, nb, tp.get("ref_smoother"), tp.get("ref_cycle_post"), args.tol)
+                            % (ne, nb, "even-odd form (dense 4096^2 Schur inverse)"
+                               if tp.get("ref_coarsest") == "eo" else "dense 8192^2 inverse",
+                               tp.get("ref_smoother"), tp.get("ref_cycle_post"), args.tol)
                             if args.workload == "config2" else
                             "synthetic %dx%d random U(1) lattice (sigma 0.204, m -0.05), %d x %d plain "
                             "Hutchinson probes/GPU/step, GPU-side adaptive MG setup, fp64, tol %.0e"
@@ -649,11 +654,13 @@ def other_configs(args, mg, n, device_index):
         mg2, A2, tp2, _, n2, ts = build_problem("config2", args, device_index, 1)
         try:
             r = secondary("BASELINE config 2 as written: plain Hutchinson (k=0), 2-level multigrid 32768 -> "
-                          "8192 (reference aggregation), dense 8192^2 coarse inverse on fp64 MFMA",
+                          "8192 (reference aggregation), coarse level solved exactly on fp64 MFMA (%s)"
+                          % ("even-odd form: dense 4096^2 inverse of its Schur complement"
+                             if tp2.get("ref_coarsest") == "eo" else "dense 8192^2 inverse"),
                           mg2, MODE_HUTCHINSON, args.nb, n2, args.tol, 2, 1)
             r["setup_s"] = ts
             r["smoother"] = {"kind": tp2.get("ref_smoother"), "degree": tp2.get("ref_cycle_post"),
-                             "restart": tp2.get("solver_restart")}
+                             "restart": tp2.get("solver_restart"), "coarsest": tp2.get("ref_coarsest")}
             return r
         finally:
             for e_ in mg2.engines:

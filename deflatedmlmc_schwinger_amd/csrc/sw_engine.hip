@@ -638,8 +638,25 @@ static int launch_ell(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   return 0;
 }
 
-// Y = coarsest_inv X : fp64 MFMA block-row kernel when the size allows, grouped-ELL otherwise
+static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, const cplx* B, cplx* Y,
+                      int nbp, int cat, cplx w);
+static int ensure_level_ws(sw_engine* h, Level& lv, int nbp);
+
+// Y = coarsest_inv X : fp64 MFMA block-row kernel when the size allows, grouped-ELL otherwise.
+// A coarsest level that carries the even-odd operators and the dense inverse of its Schur complement
+// (sw_set_eo_operator 0..3 + sw_setup_direct_level) is solved in even-odd form instead -- the same exact
+// solve at a quarter of the dense flops: b'_e = b_e - F b_o ; x_e = S^-1 b'_e ; x_o = G b_o - Hb x_e
+// (X and Y must be different arrays; the level's residual buffer is the scratch for b').
 static int apply_coarsest(sw_engine* h, Hier& H, const cplx* X, cplx* Y, int nbp) {
+  Level& lc = H.lv[H.nlevels - 1];
+  if (h->eo_direct && H.nlevels > 1 && lc.eo_op[4].set && lc.eo_op[1].set && lc.eo_op[2].set &&
+      lc.eo_op[3].set && X != Y) {
+    SWCHK(ensure_level_ws(h, lc, nbp));
+    SWCHK(launch_bsr(h, lc.eo_op[1], 1, X, X, lc.r, nbp, T_MVM, cplx{0.0, 0.0}));
+    SWCHK(launch_bsr(h, lc.eo_op[4], 0, lc.r, nullptr, Y, nbp, T_COARSEST, cplx{0.0, 0.0}));
+    SWCHK(launch_bsr(h, lc.eo_op[2], 0, X, nullptr, Y, nbp, T_MVM, cplx{0.0, 0.0}));
+    return launch_bsr(h, lc.eo_op[3], 1, Y, Y, Y, nbp, T_MVM, cplx{0.0, 0.0});
+  }
   if (!H.cinv.set) return sw_fail(h, "coarsest inverse not set");
   return launch_ell(h, H.cinv, 0, X, nullptr, Y, nbp, T_COARSEST);
 }

@@ -366,18 +366,26 @@ def block_rows_from_matrix(M, row_sites, n):
     return row_sites.astype(np.int32), kcol, vals
 
 
-def coarse_schur_operators(A, Lc):
+def coarse_schur_operators(A, Lc, even_site=None):
     """Even-odd Schur construction for a block level (5-point stencil of 16 x 16 blocks over an
-    Lc x Lc site lattice, site-major rows).  Returns dict(S, F, G, Hb as sparse n x n matrices that are
-    non-zero on the even / odd site rows only, E_sites, O_sites, E_rows, O_rows):
+    Lc x Lc site lattice, site-major rows; or any operator in 16-row tiles with a two-colouring
+    `even_site` of the tiles under which equal colours do not couple).  Returns dict(S, F, G, Hb as sparse
+    n x n matrices that are non-zero on the even / odd site rows only, E_sites, O_sites, E_rows, O_rows):
       S = D_ee - A_eo D_oo^-1 A_oe,  F = A_eo D_oo^-1,  G = D_oo^-1,  Hb = D_oo^-1 A_oe."""
     A = sp.csr_matrix(A)
     n = A.shape[0]
-    ns = Lc * Lc
-    if n != ns * 16:
-        raise Exception("block level of %d rows is not %d sites x 16" % (n, ns))
-    site = np.arange(ns)
-    even_site = (((site % Lc) + (site // Lc)) & 1) == 0
+    if even_site is None:
+        ns = Lc * Lc
+        if n != ns * 16:
+            raise Exception("block level of %d rows is not %d sites x 16" % (n, ns))
+        site = np.arange(ns)
+        even_site = (((site % Lc) + (site // Lc)) & 1) == 0
+    else:
+        even_site = np.asarray(even_site, dtype=bool)
+        ns = even_site.size
+        if n != ns * 16:
+            raise Exception("operator of %d rows is not %d tiles x 16" % (n, ns))
+        site = np.arange(ns)
     E_sites, O_sites = site[even_site], site[~even_site]
     row_even = np.repeat(even_site, 16)
     ME = sp.diags(row_even.astype(float))
@@ -404,6 +412,52 @@ def coarse_schur_operators(A, Lc):
     O_rows = np.nonzero(~row_even)[0]
     return {"S": S, "F": F, "G": G, "Hb": Hb, "E_sites": E_sites, "O_sites": O_sites,
             "E_rows": E_rows, "O_rows": O_rows}
+
+
+def reference_coarse_eo(P0, Ac, L, aggr_size):
+    """Even-odd form of the COARSE level of a 2-level reference hierarchy on an L x L lattice (BASELINE
+    config 2 as written: 32768 -> 8192), so that its exact solve costs a dense (n_c/2)^2 product instead of
+    n_c^2.  The reference's aggregates (multigrid.py:192-262) are runs of `aggr_size` consecutive natural
+    rows idx = s V + y L + x: strips of aggr_size sites along x at fixed (s, y), numbered
+    j = s V/a + y L/a + xb, each with 2 nvec coarse dofs.  The two spin strips of one (y, xb) couple to each
+    other and to the strips at (y, xb +- 1), (y +- 1, xb): with the coarse dofs reordered tile by tile,
+    tile t = y L/a + xb = both strips of (y, xb) (16 rows when 2 nvec = 8), the coarse operator is a
+    nearest-neighbour stencil of 16 x 16 blocks over an (L/a) x L torus and the colouring (y + xb) & 1 splits
+    it (L/a even).  Returns (pi, packed) -- pi[new coarse index] = old, packed = the four operators S, F, G,
+    Hb of the permuted A_c in MFMA block-row form for sw_set_eo_operator -- or None when the layout does not
+    fit (other aggregate sizes, odd strip counts, couplings between equal colours)."""
+    P0 = sp.csr_matrix(P0)
+    Ac = sp.csr_matrix(Ac)
+    n0, nc = P0.shape
+    V = L * L
+    if n0 != 2 * V or aggr_size <= 0 or L % aggr_size or n0 % aggr_size:
+        return None
+    na = n0 // aggr_size
+    strips = L // aggr_size
+    if nc % na or 2 * (nc // na) != 16 or strips % 2 or L % 2:
+        return None
+    per = nc // na
+    nt = na // 2                                     # tiles = (y, xb) pairs
+    t = np.arange(nt)
+    new = ((t[:, None, None] * 2 + np.arange(2)[None, :, None]) * per + np.arange(per)[None, None, :])
+    oldi = ((np.arange(2)[None, :, None] * nt + t[:, None, None]) * per + np.arange(per)[None, None, :])
+    pi = np.empty(nc, dtype=np.int64)
+    pi[new.reshape(-1)] = oldi.reshape(-1)
+    even = (((t // strips) + (t % strips)) & 1) == 0
+    Ap = Ac[pi][:, pi].tocsr()
+    # equal colours must not couple (other than a tile with itself)
+    Ab = sp.bsr_matrix(Ap, blocksize=(16, 16))
+    rows = np.repeat(np.arange(nt), np.diff(Ab.indptr))
+    cols = Ab.indices
+    nz = np.abs(Ab.data).reshape(len(cols), -1).max(axis=1) > 0
+    if np.any((even[rows] == even[cols]) & (rows != cols) & nz):
+        return None
+    ops = coarse_schur_operators(Ap, None, even_site=even)
+    packed = [block_rows_from_matrix(ops["S"], ops["E_sites"], nc),
+              block_rows_from_matrix(ops["F"], ops["E_sites"], nc),
+              block_rows_from_matrix(ops["G"], ops["O_sites"], nc),
+              block_rows_from_matrix(ops["Hb"], ops["O_sites"], nc)]
+    return pi, packed
 
 
 def auto_solver_cfg(L):

@@ -155,6 +155,24 @@ class MG:
         for i in range(nlev):
             if params and params.get("use_permuted") and not isinstance(levels[i].Pperm, int):
                 rhsmaps[i] = sp.csr_matrix(levels[i].Bblock_perm @ levels[i].Pperm.transpose())
+        # Build-only key ref_coarsest = "eo" (2-level reference hierarchy on a lattice, plain / deflated
+        # Hutchinson runs): the coarse level is solved exactly in even-odd form -- dense inverse of the Schur
+        # complement of its 16-row tiles (hierarchy.reference_coarse_eo), a quarter of the dense flops of
+        # coarsest_inv.  The engine then holds the coarse dofs tile by tile (P's columns, A_c and the dense
+        # inverse permuted alike; host-side attributes keep the reference's order) and the MLMC operands
+        # of level 1 (perm, rhs map) are not uploaded.
+        self.coarse_eo = None
+        if params and params.get("ref_coarsest") == "eo" and nlev == 2 and lat is not None:
+            aggr_size = levels[0].A.shape[0] // (levels[0].P.shape[1] // int(params.get("ref_coarse_dofs", 8)))
+            self.coarse_eo = _hier.reference_coarse_eo(levels[0].P, levels[1].A, lat[0], aggr_size)
+        if self.coarse_eo is not None:
+            pi = self.coarse_eo[0]
+            up_P = {0: sp.csr_matrix(levels[0].P)[:, pi]}
+            up_A = {1: sp.csr_matrix(levels[1].A)[pi][:, pi]}
+            cinv = cinv[np.ix_(pi, pi)]
+            rhsmaps = {i: c for i, c in rhsmaps.items() if i == 0}
+        else:
+            up_P, up_A = {}, {}
         for eng in self.engines:
             eng.hier_begin(REF_HID, nlev)
             if lat is not None:
@@ -165,7 +183,7 @@ class MG:
             for i in range(nlev - 1):
                 if i > 0:
                     eng.set_csr(REF_HID, i, levels[i].A)
-                eng.set_transfer(REF_HID, i, levels[i].P)
+                eng.set_transfer(REF_HID, i, up_P.get(i, levels[i].P))
                 # MR(nu) stands in for lgmres(maxiter=smooth_iters); see DESIGN.md section 4
                 nu_post = int(params.get("ref_cycle_post", 4)) if params else 4
                 eng.set_cycle(REF_HID, i, 0, nu_post,
@@ -180,9 +198,13 @@ class MG:
                                                                                         nu_post)
                     eng.set_smoother(REF_HID, i, None, self._ref_weights[("ref", i, nu_post)])
             if nlev > 1:
-                eng.set_csr(REF_HID, nlev - 1, levels[nlev - 1].A)
+                eng.set_csr(REF_HID, nlev - 1, up_A.get(nlev - 1, levels[nlev - 1].A))
             eng.set_coarsest_inv(REF_HID, cinv)
             eng.hier_end(REF_HID)
+            if self.coarse_eo is not None:
+                for which, (tmap, kcol, vals) in enumerate(self.coarse_eo[1]):
+                    eng.set_eo_operator(REF_HID, 1, which, tmap, kcol, vals)
+                eng.setup_direct_level(REF_HID, 1)      # dense inverse of the Schur complement, on the device
             if params and params.get("ref_smoother") == "eo" and nlev > 1 and lat is not None:
                 nu_post = int(params.get("ref_cycle_post", 4))
                 # even-odd Schur-complement polynomial on the lattice level of the REFERENCE hierarchy

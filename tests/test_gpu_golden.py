@@ -112,8 +112,9 @@ def test_golden_16_permuted_level_skipping():
     assert np.max(np.abs(ests - gold)) / scale < 1e-10
 
 
-@pytest.mark.parametrize("smoother,degree,restart", [("richardson", 7, 12), ("eo", 24, 16)])
-def test_config2_as_written_two_level_plain_hutchinson(smoother, degree, restart):
+@pytest.mark.parametrize("smoother,degree,restart,coarsest",
+                         [("richardson", 7, 12, "dense"), ("eo", 24, 16, "dense"), ("eo", 24, 16, "eo")])
+def test_config2_as_written_two_level_plain_hutchinson(smoother, degree, restart, coarsest):
     """BASELINE config 2 literally: schwinger128, plain (k = 0) Hutchinson, 2-level multigrid
     32768 -> 8192 built with the reference's aggregation (multigrid.py:192-262: 32-row aggregates,
     4 test vectors x 2), dense 8192^2 coarse inverse on the fp64 matrix cores.  Per-probe values
@@ -122,7 +123,7 @@ def test_config2_as_written_two_level_plain_hutchinson(smoother, degree, restart
     complement with the outer solve on the reduced system."""
     A, tp, mg, tr1 = _setup('schwinger128', 0, {'max_nr_levels': 2, 'use_solver_hierarchy': False,
                                                 'ref_smoother': smoother, 'ref_cycle_post': degree,
-                                                'solver_restart': restart})
+                                                'solver_restart': restart, 'ref_coarsest': coarsest})
     assert [lev.A.shape[0] for lev in mg.ml.levels] == [32768, 8192]
     assert tr1 == 0.0
     n = A.shape[0]
@@ -132,12 +133,19 @@ def test_config2_as_written_two_level_plain_hutchinson(smoother, degree, restart
     gold = _c("hutch128_plain_seed123456")
     assert np.max(np.abs(ests[:6] - gold) / np.abs(gold)) < 1e-10
     assert 0 < int(itf.max()) < 200
-    # the dense 8192^2 inverse through the C ABI against NumPy
+    # the coarse solve through the C ABI against NumPy: the dense 8192^2 inverse, or (coarsest = "eo") the exact
+    # solve in even-odd form -- dense 4096^2 inverse of the Schur complement of the coarse level's 16-row tiles,
+    # formed on the device -- for which the engine holds the coarse dofs tile by tile (mg.coarse_eo[0])
     rng = np.random.default_rng(5)
     X = rng.standard_normal((3, 8192)) + 1j * rng.standard_normal((3, 8192))
     Y = mg.engine.coarsest(0, X)
-    ref = (np.asarray(mg.coarsest_inv) @ X.T).T
-    assert np.linalg.norm(Y - ref) / np.linalg.norm(ref) < 1e-12
+    cinv = np.asarray(mg.coarsest_inv)
+    if coarsest == "eo":
+        assert mg.coarse_eo is not None
+        pi = mg.coarse_eo[0]
+        cinv = cinv[np.ix_(pi, pi)]
+    ref = (cinv @ X.T).T
+    assert np.linalg.norm(Y - ref) / np.linalg.norm(ref) < (1e-11 if coarsest == "eo" else 1e-12)
 
 
 def test_benchmarked_path_full_batch_per_probe_parity():

@@ -16,15 +16,13 @@ PY
 )
   $B --cfg "$CFG" --engine-opts "$4" > $OUT/b_$1.json 2> $OUT/b_$1.err || { echo "$1 failed"; tail -3 $OUT/b_$1.err; }
 }
-run base    '[[0,10,0],[0,10,2],[0,8,0],[0,14,0]]' 3 ""
-run l1_8    '[[0,10,0],[0,8,2],[0,8,0],[0,14,0]]' 3 ""
-run l1_8b   '[[0,10,0],[0,8,2],[0,8,0],[0,12,0]]' 3 ""
-run nu11    '[[0,11,0],[0,10,2],[0,8,0],[0,14,0]]' 3 ""
-run nu9     '[[0,9,0],[0,10,2],[0,8,0],[0,14,0]]' 3 ""
-run m4      '[[0,10,0],[0,10,2],[0,8,0],[0,14,0]]' 4 ""
-run nt1     '[[0,10,0],[0,10,2],[0,8,0],[0,14,0]]' 3 "mfma3_tiles=1"
-run nt4     '[[0,10,0],[0,10,2],[0,8,0],[0,14,0]]' 3 "mfma3_tiles=4"
-run l1_8m4  '[[0,10,0],[0,8,2],[0,8,0],[0,14,0]]' 4 ""
+run l1_8     '[[0,10,0],[0,8,2],[0,8,0],[0,14,0]]' 3 ""
+run l1_8l2_6 '[[0,10,0],[0,8,2],[0,6,0],[0,14,0]]' 3 ""
+run l1_8l2_7 '[[0,10,0],[0,8,2],[0,7,0],[0,14,0]]' 3 ""
+run l1_7     '[[0,10,0],[0,7,2],[0,8,0],[0,14,0]]' 3 ""
+run l1_6     '[[0,10,0],[0,6,2],[0,8,0],[0,14,0]]' 3 ""
+run l1_8l3_10 '[[0,10,0],[0,8,2],[0,8,0],[0,10,0]]' 3 ""
+run l1_8l3_18 '[[0,10,0],[0,8,2],[0,8,0],[0,18,0]]' 3 ""
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/b_*.json")):

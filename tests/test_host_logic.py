@@ -563,3 +563,51 @@ def test_screened_stopping_rule_equals_the_reference_replay():
                 assert hit is not None and hit[0] == i_ref and hit[1] == avg_ref and hit[2] == dev_ref, trial
             else:
                 assert hit is None, trial
+
+
+def test_reference_coarse_level_in_even_odd_form_solves_the_same_system(A128):
+    """hierarchy.reference_coarse_eo (build key ref_coarsest = "eo", BASELINE config 2 as written): the coarse
+    level of the reference's 2-level aggregation (strips of 32 sites along x at fixed spin and y, 8 coarse dofs
+    each) reordered tile by tile -- both spin strips of one (y, x-strip) = 16 rows -- is a nearest-neighbour
+    stencil of 16 x 16 blocks that two colours split; x_e = S^-1 (b_e - F b_o), x_o = G b_o - Hb x_e with the
+    packed operators must equal the sparse-LU solve of the permuted coarse operator; pi is a permutation that
+    keeps the 8 dofs of an aggregate together; layouts it does not fit are refused."""
+    import scipy.sparse.linalg as spla
+    n = A128.shape[0]
+    rng = np.random.default_rng(0)
+    tv = rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4))
+    P = hierarchy.prolongator_from_testvectors(tv, n, 0, [2, 8, 8], [16, 4])
+    Ac = sp.csr_matrix(P.conj().T @ A128 @ P)
+    res = hierarchy.reference_coarse_eo(P, Ac, 128, 32)
+    assert res is not None
+    pi, packed = res
+    nc = Ac.shape[0]
+    assert np.array_equal(np.sort(pi), np.arange(nc))
+    assert np.all(np.diff(pi.reshape(-1, 8), axis=1) == 1) and np.all(pi.reshape(-1, 8)[:, 0] % 8 == 0)
+    Ap = Ac[pi][:, pi].tocsr()
+    nt = nc // 16
+    t = np.arange(nt)
+    even = (((t // 4) + (t % 4)) & 1) == 0
+    # the packed operators as sparse matrices again
+    def unpack(tm, kc, vals):
+        RT, KS = kc.shape
+        rows = (tm[:, None, None, None] * 16 + np.arange(16)[None, None, None, :]) + np.zeros((1, KS, 4, 1), dtype=np.int64)
+        cols = kc[:, :, None, None] + np.arange(4)[None, None, :, None] + np.zeros((1, 1, 1, 16), dtype=np.int64)
+        v = vals.reshape(RT, KS, 4, 16)                      # [rt, ks, column in group, row in tile]
+        return sp.csr_matrix((v.reshape(-1), (rows.reshape(-1), cols.reshape(-1))), shape=(nc, nc))
+    S, F, G, Hb = (unpack(*pk) for pk in packed)
+    assert np.array_equal(np.sort(packed[0][0]), np.nonzero(even)[0])
+    E = np.nonzero(np.repeat(even, 16))[0]
+    O = np.nonzero(~np.repeat(even, 16))[0]
+    b = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+    x = spla.spsolve(Ap.tocsc(), b)
+    bp = b - F @ b
+    xe = np.linalg.solve(S[E][:, E].toarray(), bp[E])
+    xx = np.zeros_like(b)
+    xx[E] = xe
+    xx[O] = (G @ b - Hb @ xx)[O]
+    assert np.linalg.norm(xx - x) / np.linalg.norm(x) < 1e-12
+    assert hierarchy.reference_coarse_eo(P, Ac, 128, 64) is None          # other aggregate size
+    Pbad = sp.csr_matrix(P)[:, : nc - 8]
+    assert hierarchy.reference_coarse_eo(Pbad, Ac[: nc - 8][:, : nc - 8], 128, 32) is None
+

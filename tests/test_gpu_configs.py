@@ -113,14 +113,18 @@ def test_wide_batch_on_the_512_lattice_walks_the_strips_chunk_by_chunk():
     eng.close()
 
 
-def test_config3_as_written_two_level_mlmc_difference():
+@pytest.mark.parametrize("coarsest", ["dense", "eo"])
+def test_config3_as_written_two_level_mlmc_difference(coarsest):
     """BASELINE config 3 literally: schwinger128, a 2-level hierarchy 32768 -> 8192 (the
     reference's aggregation), the MLMC difference probe e = x^H A_0^-1 C x - x^H P A_c^-1 R C x with the
-    coarse solve done by the dense 8192^2 inverse on the matrix cores, against the oracle's restatement of
-    utils.py:252-361 with sparse-LU solves -- and the direct coarse term tr(Pperm^H A_c^-1 Bblock_perm)
-    (stoch_trace.py:428-435) so that difference + coarse term reproduce the exact trace."""
+    coarse solve done by the dense 8192^2 inverse on the matrix cores -- or (build key ref_coarsest = "eo")
+    exactly in even-odd form with the dense 4096^2 inverse of the coarse level's Schur complement --, against
+    the oracle's restatement of utils.py:252-361 with sparse-LU solves -- and the direct coarse term
+    tr(Pperm^H A_c^-1 Bblock_perm) (stoch_trace.py:428-435) so that difference + coarse term reproduce the
+    exact trace."""
     params = gateway.set_params('schwinger128')
     params['function_tol'] = 1e-12
+    params['ref_coarsest'] = coarsest
     params.update({'max_nr_levels': 2, 'nr_deflat_vctrs': 0})
     A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
     tp = utils.trace_params_from_params(params, "mlmc")
@@ -130,6 +134,7 @@ def test_config3_as_written_two_level_mlmc_difference():
              sys_type='schwinger', params=tp)
     levels = mg.ml.levels
     assert [lev.A.shape[0] for lev in levels] == [32768, 8192]
+    assert (mg.coarse_eo is not None) == (coarsest == "eo")
     cinv = np.asarray(mg.coarsest_inv)
     lu = rp.LUSolver(A)
     n = A.shape[0]

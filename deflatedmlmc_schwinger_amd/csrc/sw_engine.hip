@@ -306,6 +306,11 @@ struct sw_engine {
   // reported at tol (multigrid.py:347-366).  1: the reference's stopping point; 0.1: per-probe estimates
   // to 1e-10 relative even where the estimate cancels to a small number
   double stop_factor = 1.0;
+  // directly solved levels (sw_setup_level_inverse): the measured ||b - A x|| / ||b|| of the last such solve
+  // per right-hand side, and how often the refinement did not reach the tolerance and the iterative path
+  // took over
+  std::vector<double> direct_relres;
+  int64_t direct_fallbacks = 0;
   void* comm = nullptr;      // RCCL communicator (sw_comm_init), one rank per engine
   double* d_stats = nullptr; // [4] all-reduce buffer
 };
@@ -2525,7 +2530,7 @@ int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, co
   H.f32_valid = H.even_valid = false;
   if (level + 1 >= H.nlevels) return sw_fail(h, "no level below %d", level);
   if (!blk_rows || !pcols || !pmap || nblocks <= 0 || rpb <= 0) return sw_fail(h, "bad arguments");
-  if (rpb > 256) return sw_fail(h, "aggregate blocks of %d rows exceed the QR kernel's 256", rpb);
+  if (rpb > 512) return sw_fail(h, "aggregate blocks of %d rows exceed the QR kernel's 512", rpb);
   if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) return sw_fail(h, "bad group size %d", G);
   HIPCHK(hipSetDevice(h->device));
   Level& lf = H.lv[level];
@@ -2566,7 +2571,8 @@ int sw_setup_transfer(sw_engine* h, int hid, int level, int nblocks, int rpb, co
                      (const cplx*)lf.tv, 64, (const int*)R.cols, nblocks, rpb, Q, R.vals)
     if (rpb <= 64) QR_LAUNCH(1);
     else if (rpb <= 128) QR_LAUNCH(2);
-    else QR_LAUNCH(4);
+    else if (rpb <= 256) QR_LAUNCH(4);
+    else QR_LAUNCH(8);      // 8 x 8 aggregates of a block level (BASELINE config 5's 3-level hierarchy)
 #undef QR_LAUNCH
     KLAUNCH_CHECK();
   }
@@ -3562,6 +3568,41 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
   return sw_fail(h, "unknown option %s", name);
 }
 
+// Current value of an engine switch (the counterpart of sw_set_option: what a caller saves before an A/B run
+// and restores afterwards); "direct_fallbacks": how often a directly solved level missed the tolerance
+// and the iterative path took over (read-only).
+int sw_get_option(sw_engine* h, const char* name, double* value) {
+  if (!h || !name || !value) return 1;
+  struct Ent { const char* name; double v; };
+  const Ent tab[] = {
+      {"use_mfma", (double)h->use_mfma}, {"bsr_map", (double)h->bsr_map}, {"dense_map", (double)h->dense_map},
+      {"bsr_sub", (double)h->bsr_sub}, {"bsr_stages", (double)h->bsr_stages},
+      {"dense_stages", (double)h->dense_stages}, {"bsr_nt", (double)h->bsr_nt}, {"bsr_xreg", (double)h->bsr_xreg},
+      {"p_even", (double)h->p_even}, {"ell_order", (double)h->ell_order}, {"bench_what", (double)h->bench_what},
+      {"bench_mode", (double)h->bench_mode}, {"stencil_nt", (double)h->stencil_nt},
+      {"stencil_spw", (double)h->stencil_spw}, {"stencil_tile", (double)h->stencil_tile}, {"cgs2", (double)h->cgs2},
+      {"inner_cgs2", (double)h->inner_cgs2}, {"eo_direct", (double)h->eo_direct}, {"eo_solve", (double)h->eo_solve},
+      {"pyth_last", (double)h->pyth_last}, {"precond_f32", (double)h->precond_f32},
+      {"f32_tiles", (double)h->f32_tiles}, {"f32_splitk", (double)h->f32_splitk},
+      {"dot_blocks", (double)g_dot_blocks}, {"f32_krylov", (double)h->f32_krylov},
+      {"f32_pairs", (double)h->f32_pairs}, {"f32_stages", (double)h->f32_stages},
+      {"f32_dense_stages", (double)h->f32_dense_stages}, {"stop_factor", h->stop_factor},
+      {"fused_reduce", (double)h->fused_reduce}, {"eo_skew", (double)h->eo_skew},
+      {"direct_small", (double)h->direct_small}, {"gram_cycle", (double)h->gram_cycle},
+      {"lgmres_aug", (double)h->lgmres_aug}, {"verify", (double)h->verify}, {"lazy_sync", (double)h->lazy_sync},
+      {"mfma_3m", (double)h->mfma_3m}, {"eo_skew_chunk", (double)h->eo_skew_chunk},
+      {"gj_block", (double)h->gj_block}, {"eo_product", (double)h->eo_product},
+      {"mfma3_tiles", (double)h->mfma3_tiles}, {"mfma_ops", (double)h->mfma_ops},
+      {"mfma_small_tiles", (double)h->mfma_small_tiles}, {"mfma_tiles", (double)h->mfma_tiles},
+      {"direct_fallbacks", (double)h->direct_fallbacks}};
+  for (const Ent& e : tab)
+    if (std::strcmp(name, e.name) == 0) {
+      *value = e.v;
+      return 0;
+    }
+  return sw_fail(h, "unknown option %s", name);
+}
+
 int sw_set_deflation(sw_engine* h, int k, const double* U) {
   SWCHK(check_hier(h, 0, 0, false));
   if (k < 0 || k > SW_MAX_DEFL) return sw_fail(h, "deflation rank %d out of [0,%d]", k, SW_MAX_DEFL);
@@ -4125,7 +4166,36 @@ static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, 
     SWCHK(launch_bsr(h, lv.dinv, 0, lv.r, nullptr, lv.t, nbp, T_COARSEST, cplx{0.0, 0.0}));
     SWCHK(vec_add(h, X, lv.t, X, lv.n, nbp));
     if (total) *total = 1;
-    return 0;
+    // The refinement step takes the inverse's own residual (eps * cond) below the solver tolerance on the
+    // operators this was built for; that is MEASURED here, not assumed: ||b - A x|| / ||b|| per right-hand
+    // side, further refinement steps while any of them is above stop_factor * tol, and the multigrid-
+    // preconditioned FGMRES of the general path if three more steps do not get there.
+    SWCHK(ensure_small(h, nbp));
+    h->direct_relres.assign(nbp, 0.0);
+    for (int pass = 0;; ++pass) {
+      SWCHK(apply_op(h, lv, 1, X, B, lv.r, nbp));
+      SWCHK(dot_into(h, lv.r, lv.r, lv.n, nbp, h->small));
+      SWCHK(dot_into(h, B, B, lv.n, nbp, h->small + nbp));
+      SWCHK(stream_sync(h));
+      std::vector<std::complex<double>> nn(2 * (size_t)nbp);
+      HIPCHK(hipMemcpy(nn.data(), h->small, sizeof(cplx) * 2 * nbp, hipMemcpyDeviceToHost));
+      double worst = 0.0;
+      for (int j = 0; j < nbp; ++j) {
+        const double b2 = nn[nbp + j].real(), r2 = nn[j].real();
+        const double rr = b2 > 0.0 ? std::sqrt(r2 / b2) : 0.0;
+        h->direct_relres[j] = rr;
+        worst = std::max(worst, rr);
+      }
+      if (!(worst > tol * h->stop_factor)) return 0;
+      if (pass == 3) break;
+      SWCHK(launch_bsr(h, lv.dinv, 0, lv.r, nullptr, lv.t, nbp, T_COARSEST, cplx{0.0, 0.0}));
+      SWCHK(vec_add(h, X, lv.t, X, lv.n, nbp));
+    }
+    h->direct_relres.clear();      // the iterative path reports its own residuals
+    h->direct_fallbacks++;
+    const int mfb = std::min(h->restart, std::max(1, maxiter));
+    SWCHK(ensure_krylov(h, lv.sws, mfb, lv.n, nbp, true));
+    return fgmres(h, H, level0, B, X, tol, maxiter, mfb, true, lv.sws, nbp, total);
   }
   const int m = std::min(h->restart, std::max(1, maxiter));
   SWCHK(ensure_krylov(h, lv.sws, m, lv.n, nbp, true));
@@ -4167,10 +4237,18 @@ int sw_solve(sw_engine* h, int hid, int level0, int nb, const double* B, double*
   int total = 0;
   SWCHK(solve_dev(h, hid, level0, a, b, tol, maxiter, nbp, &total));
   SWCHK(unpack_host(h, lv, nb, b, X, nbp));
-  if ((level0 == H.nlevels - 1 && H.nlevels > 1) || level_is_direct(h, H, level0)) {
+  if (level0 == H.nlevels - 1 && H.nlevels > 1) {
     for (int j = 0; j < nb; ++j) {
       if (iters) iters[j] = 1;
       if (relres) relres[j] = 0.0;
+    }
+    return 0;
+  }
+  if (level_is_direct(h, H, level0) && (int)h->direct_relres.size() >= nb) {
+    // directly solved level: iteration count 1 as for the coarsest level, the MEASURED residual
+    for (int j = 0; j < nb; ++j) {
+      if (iters) iters[j] = 1;
+      if (relres) relres[j] = h->direct_relres[j];
     }
     return 0;
   }

@@ -98,6 +98,7 @@ def load_library():
     sig("sw_set_rhsmap", i32, vp, i32, i32, vp, vp, vp)
     sig("sw_set_solver", i32, vp, i32, i32)
     sig("sw_set_option", i32, vp, C.c_char_p, dbl)
+    sig("sw_get_option", i32, vp, C.c_char_p, P(dbl))
     sig("sw_apply_dirac", i32, vp, i32, i32, i32, vp, vp)
     sig("sw_restrict", i32, vp, i32, i32, i32, vp, vp)
     sig("sw_prolong", i32, vp, i32, i32, i32, vp, vp)
@@ -146,7 +147,7 @@ EXPORTED_SYMBOLS = (
     "sw_set_lattice", "sw_set_csr", "sw_set_transfer", "sw_set_coarsest_inv", "sw_set_cycle",
     "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator", "sw_setup_eo_operators", "sw_apply_eo_operator",
     "sw_get_level_bsr", "sw_setup_testvectors", "sw_setup_transfer",
-    "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_setup_direct_level", "sw_setup_level_inverse", "sw_setup_arnoldi", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option",
+    "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_setup_direct_level", "sw_setup_level_inverse", "sw_setup_arnoldi", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option", "sw_get_option",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_kernel_work", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -389,6 +390,12 @@ class Engine:
 
     def set_option(self, name, value):
         self._chk(self._lib.sw_set_option(self._h, name.encode(), float(value)), "sw_set_option")
+
+    def get_option(self, name):
+        """Current value of an engine switch (save before an A/B run, restore afterwards)."""
+        v = C.c_double(0.0)
+        self._chk(self._lib.sw_get_option(self._h, name.encode(), C.byref(v)), "sw_get_option")
+        return float(v.value)
 
     # -- building blocks -------------------------------------------------------------------
     def _io(self, X, n_in):

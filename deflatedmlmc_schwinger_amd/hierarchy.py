@@ -699,16 +699,38 @@ TUNED_SOLVER_CFG_128 = {
 # even-odd Schur complement (sw_set_eo_smoother) instead of the full operator.
 
 
-def synthetic_solver_cfg(L, nu0=10, setup="device"):
+def synthetic_solver_cfg(L, nu0=10, setup="device", levels=None):
     """Solver hierarchy for a synthetic L x L lattice (BASELINE config 5; bench.py --workload synthetic
     and the full-size GPU test use the same one): 8 x 8 site aggregates once, then 2 x 2 until the
     coarsest level is 16 x 16 sites (4096 rows); every level smoothed on its even-odd Schur complement
     (operators built on the device), a 2-step K-cycle around the solve of level 1, plain V-cycle below.
-    1024^2: levels 2097152 / 262144 / 65536 / 16384 / 4096 (profiles/r02_synthetic_lattices.txt)."""
+    1024^2: levels 2097152 / 262144 / 65536 / 16384 / 4096 (profiles/r02_synthetic_lattices.txt).
+
+    levels = 3: BASELINE config 5 AS WRITTEN ("3-level MG"): 8 x 8 site aggregates, then ONE coarsening of
+    the block level straight to 16 x 16 sites (1024^2: 8 x 8 coarse sites per aggregate, blocks of 512 rows
+    for the per-aggregate QR), levels 2097152 / 262144 / 4096.  The 262144-row level then has to carry what
+    the three levels below it carry in the five-level hierarchy: more Schur steps and a longer K-cycle."""
     a0 = 8 if L % 8 == 0 and L // 8 >= 16 else 4
+    base = {"smoother": "richardson", "restart": 3, "setup": setup,
+            # (relaxation sweeps + one converged refinement pass: see TUNED_SOLVER_CFG_128)
+            "setup_sweeps": 3, "setup_tol": 0.0, "setup_maxiter": 32, "setup_refine": 1}
+    if levels == 3:
+        Lc = L // a0
+        if Lc % 16 or Lc // 16 > 8:
+            raise Exception("no three-level hierarchy for a %d x %d lattice (coarse extent %d)" % (L, L, Lc))
+        a1 = Lc // 16
+        # profiles/r04_ab_sessions.txt (r04b): Schur steps and K-cycle length of the 262144-row level
+        nu1 = int(os.environ.get("SW_SYNTH3_NU1", "16"))
+        k1 = int(os.environ.get("SW_SYNTH3_K1", "4"))
+        return dict(base, coarsening=[[a0, 8], [a1, 8]], cycle=[[0, nu0, 0], [0, nu1, k1]],
+                    eo_levels=[0, 1])
+    if levels not in (None, 0):
+        want = int(levels)
+    else:
+        want = None
     depth = [[a0, 8]]
     Lc = L // a0
-    while Lc > 16 and Lc % 8 == 0:
+    while Lc > 16 and Lc % 8 == 0 and (want is None or len(depth) < want - 1):
         depth.append([2, 8])
         Lc //= 2
     nsm = len(depth)
@@ -717,10 +739,7 @@ def synthetic_solver_cfg(L, nu0=10, setup="device"):
     cyc = [[0, nu0, 0]] + [[0, 8, 2 if i == 1 and i < nsm - 1 else 0] for i in range(1, nsm)]
     if nsm > 1:
         cyc[-1] = [0, 14, 0]
-    return {"coarsening": depth, "cycle": cyc, "smoother": "richardson", "restart": 3,
-            "eo_levels": list(range(nsm)), "setup": setup,
-            # (relaxation sweeps + one converged refinement pass: see TUNED_SOLVER_CFG_128)
-            "setup_sweeps": 3, "setup_tol": 0.0, "setup_maxiter": 32, "setup_refine": 1}
+    return dict(base, coarsening=depth, cycle=cyc, eo_levels=list(range(nsm)))
 
 
 def _site_prolongator(Al, Lf, hd, agg, nvec, tv, fine_level):

@@ -212,6 +212,10 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *   sw_bench_dirac: "bench_mode" (0 Y=AX, 1 residual, 2 smoother step), "bench_what" (operator / R / P /
  *                  coarsest) */
 int sw_set_option(sw_engine* h, const char* name, double value);
+/* Current value of a switch (save / restore around A/B runs); also the read-only counter
+ * "direct_fallbacks": solves on a directly solved level (sw_setup_level_inverse) whose measured residual stayed
+ * above the tolerance after four refinement steps and that were handed to the iterative path instead. */
+int sw_get_option(sw_engine* h, const char* name, double* value);
 
 /* ---- building blocks (host buffers, reference ordering) -------------------------------- */
 /* Y = A_level X.  Replaces MG.matvec (multigrid.py:552-557) and the residual SpMVs at

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from deflatedmlmc_schwinger_amd import engine
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -34,20 +34,24 @@ def _relerr(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
 
 
-def test_config5_full_size_synthetic_1024_lattice():
+@pytest.mark.parametrize("nlevels,nb", [(5, 128), (3, 128)])
+def test_config5_full_size_synthetic_1024_lattice(nlevels, nb):
     """BASELINE config 5's lattice at its written size: synthetic 1024^2 random U(1) gauge
-    field (seed 2024, sigma 0.204: mean plaquette ~0.92; m = -0.05), 2 097 152 unknowns, the five-level
-    hierarchy bench.py --workload synthetic uses, built on the device.  No LU at this size; instead
+    field (seed 2024, sigma 0.204: mean plaquette ~0.92; m = -0.05), 2 097 152 unknowns, at the batch width
+    of bench.py's records (128 probes), through (5) the five-level hierarchy bench.py --workload synthetic
+    uses and (3) config 5 AS WRITTEN, a three-level hierarchy 2 097 152 -> 262 144 -> 4 096
+    (hierarchy.synthetic_solver_cfg(L, levels=3)), both built on the device.  No LU at this size; instead
     (i) the probe codes generated on the device are np.random's legacy stream bit for bit,
     (ii) the TRUE residual of every returned solution, recomputed on the host with the CSR operator
         assembled from the links, is below 5e-12 (tol 1e-12 on the engine's own residual),
     (iii) the estimates of the probe driver equal x^H z recomputed on the host from the solutions."""
-    L, mass, nb = 1024, -0.05, 64
+    L, mass = 1024, -0.05
     U1, U2 = matrix.synthetic_links(L, 0.204, 2024)
-    cfg = hierarchy.synthetic_solver_cfg(L)
+    cfg = hierarchy.synthetic_solver_cfg(L, levels=3 if nlevels == 3 else None)
     mg = MG((L, mass, U1, U2))
     mg.setup_solver_only(cfg, device=0, engines=1)
-    assert mg.solver_info["levels"] == [2097152, 262144, 65536, 16384, 4096]
+    assert mg.solver_info["levels"] == ([2097152, 262144, 4096] if nlevels == 3 else
+                                        [2097152, 262144, 65536, 16384, 4096])
     eng = mg.engine
     n = 2 * L * L
     eng.stream_set(ProbeStream(123456).window())
@@ -60,7 +64,7 @@ def test_config5_full_size_synthetic_1024_lattice():
     ref_codes = (2 * np.random.randint(2, size=(nb, n)) - 1).astype(np.int8)
     assert np.array_equal(codes, ref_codes)                                  # (i)
     del ref_codes
-    assert 1 <= itf.min() and itf.max() <= 20, (itf.min(), itf.max())
+    assert 1 <= itf.min() and itf.max() <= (20 if nlevels == 5 else 40), (itf.min(), itf.max())
     B = codes.astype(np.complex128)
     X, its, relres = eng.solve(SOLVER_HID, 0, B, 1e-12, 1000)
     assert relres.max() < 1e-12
@@ -70,7 +74,8 @@ def test_config5_full_size_synthetic_1024_lattice():
     for k0 in range(0, nb, 8):                                               # (ii), 8 columns at a time
         R = B[k0:k0 + 8].T - A @ X[k0:k0 + 8].T
         worst = max(worst, float(np.max(np.linalg.norm(R, axis=0) / np.linalg.norm(B[k0:k0 + 8].T, axis=0))))
-    print("1024^2: worst true relative residual %.2e, iterations %d..%d" % (worst, its.min(), its.max()))
+    print("1024^2, %d levels, %d probes: worst true relative residual %.2e, iterations %d..%d"
+          % (nlevels, nb, worst, its.min(), its.max()))
     assert worst < 5e-12
     e_host = np.einsum("kn,kn->k", B, X)                                     # (iii): probes are real
     assert np.max(np.abs(e_host - ests) / np.abs(e_host)) < 1e-10

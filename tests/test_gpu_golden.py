@@ -113,7 +113,11 @@ def test_golden_16_permuted_level_skipping():
 
 
 @pytest.mark.parametrize("smoother,degree,restart,coarsest",
-                         [("richardson", 7, 12, "dense"), ("eo", 24, 16, "dense"), ("eo", 24, 16, "eo")])
+                         [("richardson", 7, 12, "dense"), ("eo", 24, 16, "dense"), ("eo", 24, 16, "eo"),
+                          # exactly what bench.py's config2_as_written record times (build_problem): the
+                          # degree-48 polynomial whose weights are fitted on the host through the engine's
+                          # Schur operator (beyond the device Arnoldi's 32 vectors), product form, restart 16
+                          ("eo", 48, 16, "eo")])
 def test_config2_as_written_two_level_plain_hutchinson(smoother, degree, restart, coarsest):
     """BASELINE config 2 literally: schwinger128, plain (k = 0) Hutchinson, 2-level multigrid
     32768 -> 8192 built with the reference's aggregation (multigrid.py:192-262: 32-row aggregates,

@@ -311,6 +311,12 @@ struct sw_engine {
   // took over
   std::vector<double> direct_relres;
   int64_t direct_fallbacks = 0;
+  // device eigensolver (sw_eig_*): three [n][64] block buffers on one (hierarchy, level), the gamma_3 signs
+  // in that level's row order, the partial sums of the block Gram kernel
+  cplx* eig_buf[3] = {nullptr, nullptr, nullptr};
+  signed char* eig_sign = nullptr;
+  cplx* eig_small = nullptr;     // [64*64] reduced Gram matrix / rotation
+  int eig_hid = -1, eig_level = -1, eig_n = 0;
   void* comm = nullptr;      // RCCL communicator (sw_comm_init), one rank per engine
   double* d_stats = nullptr; // [4] all-reduce buffer
 };
@@ -2770,20 +2776,30 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   H.f32_valid = H.even_valid = false;
   Level& lv = H.lv[H.nlevels - 1];
   const EllOp& A = lv.A;
-  if (H.nlevels < 2 || !A.set || A.bsr_KS <= 0) return sw_fail(h, "coarsest level has no block-row operator");
+  if (H.nlevels < 2 || !A.set) return sw_fail(h, "coarsest level has no operator");
   const int n = lv.n;
   if (n % 16) return sw_fail(h, "coarsest size %d is not a multiple of 16", n);
   if (n > 8192) return sw_fail(h, "coarsest size %d too large for the in-engine dense inverse", n);
   cplx* D = nullptr;
   SWCHK(dev_realloc(h, &D, (size_t)n * n));
   HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
-  {
+  if (A.bsr_KS > 0 && !A.bsr_tmap) {
     LaunchScope ls(h, T_OTHER);
     const int items = (n / 16) * A.bsr_KS;
     hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
                        dim3(SW_BLOCK), 0, h->stream, (const cplx*)A.bsr_vals, (const int*)A.bsr_kcol,
                        n / 16, A.bsr_KS, n, D, (const int*)nullptr, (const int*)nullptr);
     KLAUNCH_CHECK();
+  } else if (A.cols && A.vals) {
+    // a coarsest operator handed over as CSR (sw_set_csr: the reference hierarchy's R A P)
+    LaunchScope ls(h, T_OTHER);
+    const size_t total = (size_t)A.ngroups * A.K * A.G;
+    hipLaunchKernelGGL(swk::k_ell_to_dense, dim3((unsigned)((total + SW_BLOCK - 1) / SW_BLOCK)), dim3(SW_BLOCK), 0,
+                       h->stream, (const int*)A.cols, (const cplx*)A.vals, A.K, A.G, A.ngroups, n, D);
+    KLAUNCH_CHECK();
+  } else {
+    (void)dev_free(h, D);
+    return sw_fail(h, "coarsest operator in neither grouped-ELL nor full block-row form");
   }
   if (gj_invert(h, D, n) != 0) {
     (void)dev_free(h, D);
@@ -2805,6 +2821,43 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   }
   op.bsr_KS = KS;
   op.set = true;
+  SWCHK(stream_sync(h));
+  SWCHK(dev_free(h, D));
+  return 0;
+}
+
+// The dense coarsest inverse the engine holds (set by the caller or formed on the device) as a row-major
+// complex128[n*n] host array: multigrid.py:342-344's coarsest_inv for callers that read the attribute
+// (stoch_trace.py:428-435 traces it directly).
+int sw_get_coarsest_inv(sw_engine* h, int hid, double* dense) {
+  SWCHK(check_hier(h, hid, 0, false));
+  if (!dense) return sw_fail(h, "bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[hid];
+  const EllOp& op = H.cinv;
+  if (!op.set) return sw_fail(h, "coarsest inverse missing");
+  const int n = op.nrows;
+  cplx* D = nullptr;
+  SWCHK(dev_realloc(h, &D, (size_t)n * n));
+  HIPCHK(hipMemsetAsync(D, 0, (size_t)n * n * sizeof(cplx), h->stream));
+  if (op.bsr_KS > 0 && !op.bsr_tmap) {
+    LaunchScope ls(h, T_OTHER);
+    const size_t items = (size_t)(n / 16) * op.bsr_KS;
+    hipLaunchKernelGGL(swk::k_bsr_to_dense, dim3((unsigned)((items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK)),
+                       dim3(SW_BLOCK), 0, h->stream, (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, n / 16,
+                       op.bsr_KS, n, D, (const int*)nullptr, (const int*)nullptr);
+    KLAUNCH_CHECK();
+  } else if (op.cols && op.vals) {
+    LaunchScope ls(h, T_OTHER);
+    const size_t total = (size_t)op.ngroups * op.K * op.G;
+    hipLaunchKernelGGL(swk::k_ell_to_dense, dim3((unsigned)((total + SW_BLOCK - 1) / SW_BLOCK)), dim3(SW_BLOCK), 0,
+                       h->stream, (const int*)op.cols, (const cplx*)op.vals, op.K, op.G, op.ngroups, n, D);
+    KLAUNCH_CHECK();
+  } else {
+    (void)dev_free(h, D);
+    return sw_fail(h, "coarsest inverse in an unknown form");
+  }
+  HIPCHK(hipMemcpyAsync(dense, D, (size_t)n * n * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
   SWCHK(stream_sync(h));
   SWCHK(dev_free(h, D));
   return 0;
@@ -3566,6 +3619,156 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     return 0;
   }
   return sw_fail(h, "unknown option %s", name);
+}
+
+// ---- device eigensolver: block subspace iteration with the engine's own batched solves as the
+// shift-invert (the counterpart of eigs(A_l, k, sigma=0) at multigrid.py:174 and of
+// eigsh(gamma_3 A, k, sigma=0) at utils.py:140).  The engine supplies the O(n) work on blocks of 64
+// vectors -- W = Op^-1 V, the 64 x 64 Gram matrices V^H W, W^H W, block rotations V <- W Y -- the caller
+// the 64 x 64 dense algebra in between (Rayleigh-Ritz, Cholesky-QR).
+static int solve_dev(sw_engine* h, int hid, int level0, const cplx* B, cplx* X, double tol, int maxiter,
+                     int nbp, int* total);
+static int eig_check(sw_engine* h, int a) {
+  if (h->eig_n <= 0 || !h->eig_buf[0]) return sw_fail(h, "sw_eig_begin has not been called");
+  if (a < 0 || a > 2) return sw_fail(h, "block buffer index %d out of 0..2", a);
+  return 0;
+}
+
+int sw_eig_begin(sw_engine* h, int hid, int level, uint64_t seed) {
+  SWCHK(check_hier(h, hid, level, true));
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[hid].lv[level];
+  if (lv.n <= 0 || (lv.n & 3)) return sw_fail(h, "level %d has n = %d (a multiple of 4 is needed)", level, lv.n);
+  const size_t cnt = (size_t)lv.n * 64;
+  for (int q = 0; q < 3; ++q) SWCHK(dev_realloc(h, &h->eig_buf[q], cnt));
+  SWCHK(dev_realloc(h, &h->eig_small, (size_t)4096));
+  // gamma_3 = +1 on the first half of the REFERENCE order, -1 on the second (multigrid.py:130-133)
+  std::vector<signed char> sg(lv.n);
+  for (int i = 0; i < lv.n; ++i) {
+    const int r = lv.h_rowmap.empty() ? i : lv.h_rowmap[i];
+    sg[r] = (i < lv.n / 2) ? 1 : -1;
+  }
+  SWCHK(upload(h, &h->eig_sign, (const signed char*)sg.data(), (size_t)lv.n));
+  h->eig_hid = hid;
+  h->eig_level = level;
+  h->eig_n = lv.n;
+  {
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_fill_random, dim3((lv.n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK),
+                       dim3(SW_BLOCK), 0, h->stream, h->eig_buf[0], lv.n, 64, 64,
+                       (unsigned long long)(seed ? seed : 11));
+    KLAUNCH_CHECK();
+  }
+  return stream_sync(h);
+}
+
+int sw_eig_end(sw_engine* h) {
+  if (!h) return 1;
+  for (int q = 0; q < 3; ++q) {
+    if (h->eig_buf[q]) SWCHK(dev_free(h, h->eig_buf[q]));
+    h->eig_buf[q] = nullptr;
+  }
+  if (h->eig_sign) SWCHK(dev_free(h, h->eig_sign));
+  h->eig_sign = nullptr;
+  if (h->eig_small) SWCHK(dev_free(h, h->eig_small));
+  h->eig_small = nullptr;
+  h->eig_n = 0;
+  h->eig_hid = h->eig_level = -1;
+  return 0;
+}
+
+// Overwrite the first ncols columns of block buffer `dst` with host vectors (reference order, ncols
+// contiguous vectors of length n), e.g. converged vectors of the level above as a start.
+int sw_eig_load(sw_engine* h, int dst, int ncols, const double* X) {
+  SWCHK(eig_check(h, dst));
+  if (ncols < 1 || ncols > 64 || !X) return sw_fail(h, "bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[h->eig_hid].lv[h->eig_level];
+  const int spare = dst == 2 ? 1 : 2;
+  // pack into a spare buffer (all 64 columns written, zero beyond ncols), then copy the columns over
+  SWCHK(pack_host(h, lv, ncols, X, h->eig_buf[spare], 64));
+  HIPCHK(hipMemcpy2DAsync(h->eig_buf[dst], 64 * sizeof(cplx), h->eig_buf[spare], 64 * sizeof(cplx),
+                          (size_t)ncols * sizeof(cplx), (size_t)lv.n, hipMemcpyDeviceToDevice, h->stream));
+  return stream_sync(h);
+}
+
+// dst = Op^-1 src on all 64 columns: mode 0 Op = A_level (multigrid.py:174), mode 1 Op = gamma_3 A_level
+// (utils.py:137-140; Q^-1 = A^-1 gamma_3).  Batched solve of the (hierarchy, level) to `tol`.
+int sw_eig_solve(sw_engine* h, int src, int dst, int mode, double tol, int maxiter, int32_t* iters_max) {
+  SWCHK(eig_check(h, src));
+  SWCHK(eig_check(h, dst));
+  if (src == dst) return sw_fail(h, "source and destination buffers must differ");
+  if (mode != 0 && mode != 1) return sw_fail(h, "mode must be 0 (A) or 1 (gamma_3 A)");
+  HIPCHK(hipSetDevice(h->device));
+  Hier& H = h->hier[h->eig_hid];
+  Level& lv = H.lv[h->eig_level];
+  const cplx* rhs = h->eig_buf[src];
+  if (mode == 1) {
+    cplx* tmp = h->eig_buf[3 - src - dst];
+    LaunchScope ls(h, T_OTHER);
+    hipLaunchKernelGGL(swk::k_row_sign, dim3((lv.n + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK, 1),
+                       dim3(SW_BLOCK), 0, h->stream, rhs, (const signed char*)h->eig_sign, tmp, lv.n, 64);
+    KLAUNCH_CHECK();
+    rhs = tmp;
+  }
+  int total = 0;
+  SWCHK(solve_dev(h, h->eig_hid, h->eig_level, rhs, h->eig_buf[dst], tol, maxiter, 64, &total));
+  SWCHK(stream_sync(h));
+  if (iters_max) *iters_max = total;
+  return 0;
+}
+
+// out[64*64] (row-major complex128) = buf_a^H buf_b
+int sw_eig_gram(sw_engine* h, int a, int b, double* out) {
+  SWCHK(eig_check(h, a));
+  SWCHK(eig_check(h, b));
+  if (!out) return sw_fail(h, "bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  const int n = h->eig_n;
+  int rpb = std::max(64, ((n + 255) / 256 + 3) & ~3);     // ~256 row blocks, multiples of 4 rows
+  const int P = (n + rpb - 1) / rpb;
+  SWCHK(ensure_partial(h, (size_t)P * 4096 * sizeof(cplx)));
+  {
+    LaunchScope ls(h, T_DOTS);
+    hipLaunchKernelGGL(swk::k_block_gram, dim3(P, 4), dim3(SW_BLOCK), 0, h->stream,
+                       (const cplx*)h->eig_buf[a], (const cplx*)h->eig_buf[b], n, rpb, h->partial);
+    KLAUNCH_CHECK();
+  }
+  {
+    LaunchScope ls(h, T_DOTS);
+    hipLaunchKernelGGL(swk::k_block_gram_reduce, dim3(16), dim3(SW_BLOCK), 0, h->stream,
+                       (const cplx*)h->partial, P, h->eig_small);
+    KLAUNCH_CHECK();
+  }
+  HIPCHK(hipMemcpyAsync(out, h->eig_small, 4096 * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+  return stream_sync(h);
+}
+
+// buf_dst = buf_src Y (sub < 0) or buf_dst = buf_sub - buf_src Y, Y[64*64] row-major complex128 (dst != src)
+int sw_eig_rotate(sw_engine* h, int src, const double* Y, int dst, int sub) {
+  SWCHK(eig_check(h, src));
+  SWCHK(eig_check(h, dst));
+  if (sub >= 0) SWCHK(eig_check(h, sub));
+  if (src == dst || !Y) return sw_fail(h, "bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->eig_small, Y, 4096 * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+  {
+    LaunchScope ls(h, T_AXPY);
+    hipLaunchKernelGGL(swk::k_block_rotate, dim3(std::min(2048, h->eig_n / SW_WAVES_PER_BLOCK)), dim3(SW_BLOCK),
+                       0, h->stream, (const cplx*)h->eig_buf[src], (const cplx*)h->eig_small,
+                       (const cplx*)(sub >= 0 ? h->eig_buf[sub] : nullptr), h->eig_buf[dst], h->eig_n);
+    KLAUNCH_CHECK();
+  }
+  return stream_sync(h);
+}
+
+// The first k columns of buf_src as k host vectors of length n in the reference order.
+int sw_eig_fetch(sw_engine* h, int src, int k, double* out) {
+  SWCHK(eig_check(h, src));
+  if (k < 1 || k > 64 || !out) return sw_fail(h, "bad arguments");
+  HIPCHK(hipSetDevice(h->device));
+  Level& lv = h->hier[h->eig_hid].lv[h->eig_level];
+  return unpack_host(h, lv, k, h->eig_buf[src], out, 64);
 }
 
 // Current value of an engine switch (the counterpart of sw_set_option: what a caller saves before an A/B run

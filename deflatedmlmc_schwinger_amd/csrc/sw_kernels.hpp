@@ -2553,4 +2553,93 @@ __global__ void k_est_combine(const cplx* __restrict__ a, const cplx* __restrict
   e[col] = b ? csub(a[col], b[col]) : a[col];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Block (subspace) algebra of the device eigensolver (sw_eig_*: the counterpart of ARPACK's
+// eigs / eigsh at multigrid.py:174, utils.py:140): a block of up to 64 vectors is one [n][64]
+// array (column = vector), so cross-vector products are cross-LANE products -- the one place
+// outside the coarse operators where the fp64 matrix cores are the natural tool.
+//   k_block_gram:   C[64][64] = V^H W          partial sums per row block, k_block_gram_reduce adds
+//                   them in block order (deterministic)
+//   k_block_rotate: out = W Y  or  out = C - W Y,  Y[64][64] (Ritz rotation, Cholesky-QR
+//                   back-substitution, block residual)
+//   k_row_sign:     dst = diag(sign) src       (gamma_3 in the level's row order)
+// v_mfma_f64_16x16x4_f64 operand layout as for k_bsr_mfma: lane l holds A[l&15][l>>4],
+// B[l>>4][l&15], D[(l>>4)+4r][l&15].  Here A = (V^H)[i][row], B = W[row][j]: both operands are plain
+// loads from the [n][64] arrays (16 consecutive columns of 4 consecutive rows per wave).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SW_BLOCK) void k_block_gram(const cplx* __restrict__ V,
+                                                         const cplx* __restrict__ W, int n,
+                                                         int rows_per_block,
+                                                         cplx* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int jb = threadIdx.x >> 6;       // column tile of W (wave)
+  const int ib = blockIdx.y;             // column tile of V
+  const int k = lane >> 4, c = lane & 15;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
+  sw_double4 cr = {0.0, 0.0, 0.0, 0.0}, ci = {0.0, 0.0, 0.0, 0.0};
+  const cplx* vp = V + (size_t)ib * 16 + c;
+  const cplx* wp = W + (size_t)jb * 16 + c;
+  for (int row = r0 + k; row < r1 + k; row += 4) {
+    cplx v = cmake(0.0, 0.0), w = cmake(0.0, 0.0);
+    if (row < r1) {
+      v = vp[(size_t)row * 64];
+      w = wp[(size_t)row * 64];
+    }
+    // conj(v) w = (vr wr + vi wi) + i (vr wi - vi wr)
+    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, w.x, cr, 0, 0, 0);
+    cr = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, w.y, cr, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, w.y, ci, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, w.x, ci, 0, 0, 0);
+  }
+  cplx* out = partial + (size_t)blockIdx.x * 4096;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    out[(size_t)(ib * 16 + k + 4 * r) * 64 + jb * 16 + c] = cmake(cr[r], ci[r]);
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_block_gram_reduce(const cplx* __restrict__ partial, int P,
+                                                                cplx* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 4096) return;
+  cplx s = cmake(0.0, 0.0);
+  for (int p = 0; p < P; ++p) s = cadd(s, partial[(size_t)p * 4096 + e]);
+  out[e] = s;
+}
+
+// out[row][j] = sum_i W[row][i] Y[i][j]; Y in LDS (64 KB), one wave per row, lane = j
+__global__ __launch_bounds__(SW_BLOCK) void k_block_rotate(const cplx* __restrict__ W,
+                                                           const cplx* __restrict__ Y,
+                                                           const cplx* __restrict__ Cm,
+                                                           cplx* __restrict__ out, int n) {
+  __shared__ cplx Ys[64 * 64];
+  __shared__ cplx Wr[SW_WAVES_PER_BLOCK][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 4096; e += SW_BLOCK) Ys[e] = Y[e];
+  __syncthreads();
+  // n is a multiple of 4 on every level, so the four waves of a block run the same number of rounds
+  for (int row = blockIdx.x * SW_WAVES_PER_BLOCK + wave; row < n; row += gridDim.x * SW_WAVES_PER_BLOCK) {
+    Wr[wave][lane] = W[(size_t)row * 64 + lane];
+    __syncthreads();
+    cplx acc = cmake(0.0, 0.0);
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) cfma(acc, Wr[wave][i], Ys[i * 64 + lane]);
+    // Cm given: out = Cm - W Y (the block residual W - V T of the Rayleigh-Ritz step)
+    out[(size_t)row * 64 + lane] = Cm ? csub(Cm[(size_t)row * 64 + lane], acc) : acc;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(SW_BLOCK) void k_row_sign(const cplx* __restrict__ src,
+                                                       const signed char* __restrict__ sign,
+                                                       cplx* __restrict__ dst, int n, int nbp) {
+  const int row = blockIdx.x * SW_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const size_t o = (size_t)row * nbp + (size_t)blockIdx.y * 64 + (threadIdx.x & 63);
+  const double sg = (double)sign[row];
+  const cplx v = src[o];
+  dst[o] = cmake(sg * v.x, sg * v.y);
+}
+
 }  // namespace swk

@@ -99,6 +99,14 @@ def load_library():
     sig("sw_set_solver", i32, vp, i32, i32)
     sig("sw_set_option", i32, vp, C.c_char_p, dbl)
     sig("sw_get_option", i32, vp, C.c_char_p, P(dbl))
+    sig("sw_get_coarsest_inv", i32, vp, i32, vp)
+    sig("sw_eig_begin", i32, vp, i32, i32, C.c_uint64)
+    sig("sw_eig_load", i32, vp, i32, i32, vp)
+    sig("sw_eig_solve", i32, vp, i32, i32, i32, dbl, i32, P(i32))
+    sig("sw_eig_gram", i32, vp, i32, i32, vp)
+    sig("sw_eig_rotate", i32, vp, i32, vp, i32, i32)
+    sig("sw_eig_fetch", i32, vp, i32, i32, vp)
+    sig("sw_eig_end", i32, vp)
     sig("sw_apply_dirac", i32, vp, i32, i32, i32, vp, vp)
     sig("sw_restrict", i32, vp, i32, i32, i32, vp, vp)
     sig("sw_prolong", i32, vp, i32, i32, i32, vp, vp)
@@ -148,6 +156,7 @@ EXPORTED_SYMBOLS = (
     "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator", "sw_setup_eo_operators", "sw_apply_eo_operator",
     "sw_get_level_bsr", "sw_setup_testvectors", "sw_setup_transfer",
     "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_setup_direct_level", "sw_setup_level_inverse", "sw_setup_arnoldi", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option", "sw_get_option",
+    "sw_get_coarsest_inv", "sw_eig_begin", "sw_eig_load", "sw_eig_solve", "sw_eig_gram", "sw_eig_rotate", "sw_eig_fetch", "sw_eig_end",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_kernel_work", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -334,6 +343,12 @@ class Engine:
         self._chk(self._lib.sw_setup_invert_coarsest(self._h, hid), "sw_setup_invert_coarsest")
         self.level_sizes[hid][-1] = self.level_sizes[hid][-1]
 
+    def get_coarsest_inv(self, hid, n):
+        """The dense coarsest inverse the engine holds, as an (n, n) complex128 array."""
+        out = np.empty((n, n), dtype=np.complex128)
+        self._chk(self._lib.sw_get_coarsest_inv(self._h, hid, _ptr(out)), "sw_get_coarsest_inv")
+        return out
+
     def setup_direct_level(self, hid, level):
         """Dense inverse of block level `level`'s even-odd Schur complement, formed on the device and
         installed as the level's even-odd operator 4 (the level is then solved exactly)."""
@@ -396,6 +411,41 @@ class Engine:
         v = C.c_double(0.0)
         self._chk(self._lib.sw_get_option(self._h, name.encode(), C.byref(v)), "sw_get_option")
         return float(v.value)
+
+    # -- device eigensolver (block subspace iteration; driver: setup_gpu.device_eigenpairs) ------
+    def eig_begin(self, hid, level, seed=11):
+        self._chk(self._lib.sw_eig_begin(self._h, hid, level, int(seed)), "sw_eig_begin")
+        self._eig_n = self._n(hid, level)
+
+    def eig_load(self, dst, X):
+        X = np.ascontiguousarray(np.atleast_2d(X), dtype=np.complex128)
+        self._chk(self._lib.sw_eig_load(self._h, dst, X.shape[0], _ptr(X)), "sw_eig_load")
+
+    def eig_solve(self, src, dst, mode, tol, maxiter=1000):
+        its = C.c_int32(0)
+        self._chk(self._lib.sw_eig_solve(self._h, src, dst, mode, float(tol), int(maxiter), C.byref(its)),
+                  "sw_eig_solve")
+        return int(its.value)
+
+    def eig_gram(self, a, b):
+        out = np.empty((64, 64), dtype=np.complex128)
+        self._chk(self._lib.sw_eig_gram(self._h, a, b, _ptr(out)), "sw_eig_gram")
+        return out
+
+    def eig_rotate(self, src, Y, dst, sub=-1):
+        """buf_dst = buf_src Y, or (sub >= 0) buf_dst = buf_sub - buf_src Y"""
+        Y = np.ascontiguousarray(Y, dtype=np.complex128)
+        if Y.shape != (64, 64):
+            raise EngineError("rotation matrix must be 64 x 64")
+        self._chk(self._lib.sw_eig_rotate(self._h, src, _ptr(Y), dst, sub), "sw_eig_rotate")
+
+    def eig_fetch(self, src, k):
+        out = np.empty((k, self._eig_n), dtype=np.complex128)
+        self._chk(self._lib.sw_eig_fetch(self._h, src, k, _ptr(out)), "sw_eig_fetch")
+        return out
+
+    def eig_end(self):
+        self._chk(self._lib.sw_eig_end(self._h), "sw_eig_end")
 
     # -- building blocks -------------------------------------------------------------------
     def _io(self, X, n_in):

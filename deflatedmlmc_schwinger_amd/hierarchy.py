@@ -195,8 +195,14 @@ def prolongator_from_testvectors(tv, n, i, dof, aggrs):
     return P
 
 
-def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvectors=None):
-    """multigrid.py:100-345 -> (SimpleML, coarsest_inv, testvectors)."""
+def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvectors=None, eigs_fn=None,
+                        invert=True):
+    """multigrid.py:100-345 -> (SimpleML, coarsest_inv, testvectors).
+
+    eigs_fn (optional): callable(level, A_level, nvec, tol) -> test vectors [n, nvec] or None -- the device
+    eigensolver's hook for `eigs(A_l, k, sigma=0)` (multigrid.py:174); None (or a None answer) = the
+    reference's own ARPACK + SuperLU call on the host.  invert = False leaves the dense inverse of the
+    coarsest operator (multigrid.py:342-344) to the engine (sw_setup_invert_coarsest) and returns None for it."""
     tv_type = params["test_vectors_type"]
     if tv_type not in ("EVs", "LSVs", "RSVs"):
         raise Exception("unknown type of test vectors")
@@ -223,8 +229,13 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
             ml.levels[0].perm_shift = shift0
             ml.levels[0].Pperm = shift_operator(n, shift0)
             ml.levels[0].Bblock_perm = sp.identity(n, dtype=np.complex128, format="csr")
-        if testvectors is not None:
+        tv = None
+        if testvectors is not None and i < len(testvectors) and testvectors[i] is not None:
             tv = np.asarray(testvectors[i])
+        elif tv_type == "EVs" and eigs_fn is not None:
+            tv = eigs_fn(i, Al, nvec, tolx)
+        if tv is not None:
+            pass
         elif tv_type == "EVs":
             ncv = nvec + 2 if acc_eigvs == "low" else None
             _, tv = spla.eigs(sp.csc_matrix(Al), k=nvec, which="LM", tol=tolx, maxiter=1000000,
@@ -252,7 +263,7 @@ def reference_hierarchy(A, dof, aggrs, max_levels, acc_eigvs, params, testvector
             nxt.Pperm = shift_operator(Pl.shape[1], sh)
             Bl = ml.levels[i].Pperm.transpose().conjugate() @ (Pl @ nxt.Pperm)
             nxt.Bblock_perm = sp.csr_matrix((Rl @ ml.levels[i].Bblock_perm) @ Bl)
-    coarsest_inv = np.matrix(dense_inverse(ml.levels[-1].A.toarray()))
+    coarsest_inv = np.matrix(dense_inverse(ml.levels[-1].A.toarray())) if invert else None
     return ml, coarsest_inv, used
 
 
@@ -719,8 +730,10 @@ def synthetic_solver_cfg(L, nu0=10, setup="device", levels=None):
         if Lc % 16 or Lc // 16 > 8:
             raise Exception("no three-level hierarchy for a %d x %d lattice (coarse extent %d)" % (L, L, Lc))
         a1 = Lc // 16
-        # profiles/r04_ab_sessions.txt (r04b): Schur steps and K-cycle length of the 262144-row level
-        nu1 = int(os.environ.get("SW_SYNTH3_NU1", "16"))
+        # Schur steps / K-cycle length of the 262144-row level at 1024^2, 128 probes (profiles/r04_ab_sessions.txt,
+        # r04a/b): 12/3 212, 16/4 223, 16/6 222, 24/4 262, 32/2 260, 32/4 259 probe-samples/s (25 ... 15 outer
+        # iterations): a plateau from 24 steps on
+        nu1 = int(os.environ.get("SW_SYNTH3_NU1", "24"))
         k1 = int(os.environ.get("SW_SYNTH3_K1", "4"))
         return dict(base, coarsening=[[a0, 8], [a1, 8]], cycle=[[0, nu0, 0], [0, nu1, k1]],
                     eo_levels=[0, 1])

@@ -69,7 +69,7 @@ class MG:
         self.coarsest_lev_iters = [0] * 10
         self.level_for_diff_op = 0
         self.solve_tol = 1.0e-1
-        self.coarsest_inv = []
+        self._cinv = []           # (the attribute coarsest_inv of multigrid.py:84; a lazy property here)
         self.timer = CustomTimer()
         self.skip_level = False
         # build-specific state
@@ -82,11 +82,46 @@ class MG:
         self._have_solver_hier = False
         self.maxiter_cap = 1000
         self._ref_weights = {}
+        self._lat = False           # cached hierarchy.detect_lattice(A) (False: not looked at yet)
+        self._solver_cfg_built = None
+        self._device_defl = {}      # (k, tol) -> (eigenvalues, eigenvectors) of gamma_3 A found during setup
+        self.coarse_eo = None
+        self.setup_log = {}
+
+    # the dense inverse of the coarsest operator (multigrid.py:342-344).  With the device setup it is formed on
+    # the GPU (sw_setup_invert_coarsest) and only comes to the host when somebody reads the attribute
+    # (stoch_trace.py:428-435 traces it; plain Hutchinson flows never do).
+    @property
+    def coarsest_inv(self):
+        if self._cinv is None and self.engine is not None and self.ml and len(self.ml.levels) > 1:
+            n_c = self.ml.levels[-1].A.shape[0]
+            M = self.engine.get_coarsest_inv(REF_HID, n_c)
+            if self.coarse_eo is not None:
+                # the engine holds the coarse dofs tile by tile (ref_coarsest = "eo"): back to the reference order
+                pi = self.coarse_eo[0]
+                out = np.empty_like(M)
+                out[np.ix_(pi, pi)] = M
+                M = out
+            self._cinv = np.matrix(M)
+        return self._cinv
+
+    @coarsest_inv.setter
+    def coarsest_inv(self, value):
+        self._cinv = value
+
+    def _lattice(self):
+        if self._lat is False:
+            self._lat = self._A0 if isinstance(self._A0, tuple) else _hier.detect_lattice(self._A0)
+        return self._lat
 
     # ------------------------------------------------------------------------------------
     def setup(self, dof=[2, 8, 8], aggrs=[2 * 2, 2 * 2], max_levels=3, dim=2, acc_eigvs='low',
               sys_type='schwinger', params=None):
-        """Host setup as multigrid.py:100-345, then upload to the GPU engine."""
+        """multigrid.py:100-345 -- the reference's index arithmetic on the host (aggregation, spin split,
+        Gram-Schmidt, Galerkin products), its eigensolves on the GPU where the operator is a lattice operator
+        (device_setup: level-0 test vectors and the deflation vectors by block subspace iteration with the
+        engine's own multigrid solves as the shift-invert, the coarsest inverse by Gauss-Jordan on the device),
+        on the host exactly as in the reference otherwise (params["setup_eigs"] = "reference")."""
         if params is None:
             raise Exception("setup needs the trace parameter dictionary")
         tv = params.get("mg_testvectors")
@@ -99,23 +134,130 @@ class MG:
             if hit is not None:
                 tv = [hit["tv%d" % i] for i in range(max_levels - 1)]
                 ckey = None
-        ml, cinv, used = collective_reference_hierarchy(self._A0, dof, aggrs, max_levels,
-                                                        acc_eigvs, params, tv)
+        self._cache_dir = cdir
+        t0 = time.time()
+        if self._device_setup_wanted(params):
+            ml, cinv, used = self._device_reference_hierarchy(dof, aggrs, max_levels, acc_eigvs, params, tv)
+        else:
+            ml, cinv, used = collective_reference_hierarchy(self._A0, dof, aggrs, max_levels,
+                                                            acc_eigvs, params, tv)
+        self.setup_log["reference_hierarchy_s"] = round(time.time() - t0, 4)
         if ckey is not None:
             _cache.save(cdir, "mgtv", ckey, {"tv%d" % i: np.asarray(v) for i, v in enumerate(used)})
-        self._cache_dir = cdir
         self.ml = ml
         self.coarsest_inv = cinv
         self.testvectors = used
         self.total_levels = len(ml.levels)
         self.A = ml.levels[0].A
+        t0 = time.time()
         self._upload(params)
+        self.setup_log["upload_s"] = round(time.time() - t0, 4)
+
+    # ---- device setup --------------------------------------------------------------------------
+    def _solver_cfg_of(self, params):
+        lat = self._lattice()
+        cfg = params.get("solver_cfg") if params else None
+        if (cfg is None or cfg == "auto") and lat is not None:
+            cfg = _hier.auto_solver_cfg(lat[0])
+        return cfg
+
+    def _device_setup_wanted(self, params):
+        """The device eigensolver serves this setup: a lattice operator, eigenvector test vectors (the preset's
+        type), a solver hierarchy that is itself built on the device (its multigrid solves are the
+        shift-invert operator) -- unless params["setup_eigs"] (or SW_SETUP_EIGS) says "reference"."""
+        mode = params.get("setup_eigs", os.environ.get("SW_SETUP_EIGS", "device"))
+        if mode != "device" or params.get("test_vectors_type") != "EVs":
+            return False
+        if self._lattice() is None:
+            return False
+        cfg = self._solver_cfg_of(params)
+        return isinstance(cfg, dict) and cfg.get("setup") == "device"
+
+    def _prepare_device(self, params):
+        """Engines, the lattice operator and the level-0 solver hierarchy, ahead of the reference hierarchy."""
+        device = int(params.get("device", self.device))
+        nr_engines = max(1, int(params.get("engines", 1)))
+        if self.engine is None:
+            self.engines = [_new_engine(device) for _ in range(nr_engines)]
+            self.engine = self.engines[0]
+        lat = self._lattice()
+        self.lattice = lat
+        lev = LevelML()
+        lev.A = self._A0 if not isinstance(self._A0, tuple) else None
+        self.ml = SimpleML()
+        self.ml.levels.append(lev)
+        for eng in self.engines:
+            eng.hier_begin(REF_HID, 1)
+            eng.set_lattice(REF_HID, lat[0], lat[1], lat[2], lat[3])
+            eng.hier_end(REF_HID)
+        cfg = self._solver_cfg_of(params)
+        self.upload_solver_hierarchy(cfg, params.get("solver_testvectors"))
+        self._solver_cfg_built = dict(cfg)
+
+    def device_eigenpairs(self, k, tol, hermitian=False, log=None):
+        """k eigenpairs nearest zero of A (level 0) -- or of gamma_3 A (hermitian) -- on the GPU, the level-0
+        solver hierarchy's solves as the shift-invert (setup_gpu.device_eigenpairs)."""
+        from . import setup_gpu
+        if not self._have_solver_hier:
+            raise EngineError("the device eigensolver needs the level-0 solver hierarchy")
+        return setup_gpu.device_eigenpairs(self.engine, SOLVER_HID, 0, k, tol, hermitian_g3=hermitian, log=log)
+
+    def _device_reference_hierarchy(self, dof, aggrs, max_levels, acc_eigvs, params, tv):
+        """hierarchy.reference_hierarchy with the eigensolves of the lattice level on the GPU.  Rank 0 runs
+        them (every rank holds the same deterministic solver hierarchy; one source keeps the MLMC level
+        operators identical by construction) and, while its host thread builds P_0, A_1 and the small coarse
+        levels (host ARPACK on 8192 / 2048 rows), the GPU already computes the deflation vectors the
+        estimators will ask for next.  The coarsest inverse is left to the engine (_upload)."""
+        t0 = time.time()
+        self._prepare_device(params)
+        self.setup_log["solver_hierarchy_s"] = round(time.time() - t0, 4)
+        comm = _dist.default_comm()
+        tolx = 1.0e-3 if acc_eigvs == "low" else 1.0e-9
+        kd = int(params.get("nr_deflat_vctrs", 0) or 0)
+        tol_d = params.get("defl_eigvs_tol_Hutch", 1.0e-9)
+        want_defl = kd > 0 and params.get("deflation_eigenpairs") is None and kd <= 32
+        if want_defl and self._cache_dir:
+            dkey = _cache.matrix_key(self._A0, {"k": kd, "tol": tol_d})
+            want_defl = _cache.load(self._cache_dir, "defl", dkey) is None
+        built = None
+
+        def root_job():
+            nonlocal built
+            from concurrent.futures import ThreadPoolExecutor
+            tvs = tv
+            if tvs is None:
+                log = []
+                t1 = time.time()
+                _, tv0 = self.device_eigenpairs(int(dof[1] / 2), tolx, log=log)
+                self.setup_log["eigs_level0"] = {"seconds": round(time.time() - t1, 4), "steps": log}
+                tvs = [tv0]
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                fut = pool.submit(_hier.reference_hierarchy, self._A0, dof, aggrs, max_levels, acc_eigvs,
+                                  params, tvs, None, False)
+                defl = None
+                if want_defl:
+                    dlog = []
+                    t1 = time.time()
+                    defl = self.device_eigenpairs(kd, tol_d, hermitian=True, log=dlog)
+                    self.setup_log["eigsh_deflation"] = {"seconds": round(time.time() - t1, 4), "steps": dlog}
+                t1 = time.time()
+                built = fut.result()
+                self.setup_log["host_levels_wait_s"] = round(time.time() - t1, 4)
+            return built[2], defl
+
+        tvs, defl = comm.compute_on_root(root_job)
+        if built is None:
+            built = _hier.reference_hierarchy(self._A0, dof, aggrs, max_levels, acc_eigvs, params,
+                                              testvectors=tvs, invert=False)
+        if defl is not None:
+            self._device_defl[(kd, float(tol_d))] = defl
+        return built
 
     def setup_solver_only(self, solver_cfg=None, device=0, engines=1):
         """Large synthetic lattices (BASELINE config 5): no reference (MLMC) hierarchy, only the
         level-0 operator and the solver hierarchy, built without host ARPACK / SuperLU when
         ``solver_cfg["setup"] == "adaptive"``.  Plain / deflated Hutchinson probes only."""
-        lat = _hier.detect_lattice(self._A0) if not isinstance(self._A0, tuple) else self._A0
+        lat = self._lattice()
         if lat is None:
             raise Exception("setup_solver_only needs a lattice operator")
         self.lattice = lat
@@ -148,9 +290,13 @@ class MG:
             self.engine = self.engines[0]
         levels = self.ml.levels
         nlev = len(levels)
-        lat = _hier.detect_lattice(levels[0].A)
+        lat = self._lattice()
         self.lattice = lat
-        cinv = np.asarray(self.coarsest_inv)
+        # None: the engine forms the inverse itself from the coarsest operator (sw_setup_invert_coarsest)
+        n_c = levels[-1].A.shape[0]
+        if self._cinv is None and (n_c % 16 or n_c > 8192):
+            self._cinv = np.matrix(_hier.dense_inverse(levels[-1].A.toarray()))
+        cinv = None if self._cinv is None else np.asarray(self._cinv)
         rhsmaps = {}
         for i in range(nlev):
             if params and params.get("use_permuted") and not isinstance(levels[i].Pperm, int):
@@ -169,7 +315,8 @@ class MG:
             pi = self.coarse_eo[0]
             up_P = {0: sp.csr_matrix(levels[0].P)[:, pi]}
             up_A = {1: sp.csr_matrix(levels[1].A)[pi][:, pi]}
-            cinv = cinv[np.ix_(pi, pi)]
+            if cinv is not None:
+                cinv = cinv[np.ix_(pi, pi)]
             rhsmaps = {i: c for i, c in rhsmaps.items() if i == 0}
         else:
             up_P, up_A = {}, {}
@@ -199,7 +346,10 @@ class MG:
                     eng.set_smoother(REF_HID, i, None, self._ref_weights[("ref", i, nu_post)])
             if nlev > 1:
                 eng.set_csr(REF_HID, nlev - 1, up_A.get(nlev - 1, levels[nlev - 1].A))
-            eng.set_coarsest_inv(REF_HID, cinv)
+            if cinv is not None:
+                eng.set_coarsest_inv(REF_HID, cinv)
+            else:
+                eng.setup_invert_coarsest(REF_HID)       # Gauss-Jordan on the GPU (multigrid.py:342-344)
             eng.hier_end(REF_HID)
             if self.coarse_eo is not None:
                 for which, (tmap, kcol, vals) in enumerate(self.coarse_eo[1]):
@@ -243,10 +393,15 @@ class MG:
         if (cfg is None or cfg == "auto") and lat is not None:
             cfg = _hier.auto_solver_cfg(lat[0])      # tuned, device-built where the lattice allows it
         want = True if params is None else params.get("use_solver_hierarchy", True)
-        self._have_solver_hier = False
         if want and lat is not None:
-            self.upload_solver_hierarchy(cfg, params.get("solver_testvectors") if params else None)
+            if not (self._have_solver_hier and self._solver_cfg_built == cfg):
+                # (the device setup has built it already, ahead of the reference hierarchy)
+                self._have_solver_hier = False
+                self.upload_solver_hierarchy(cfg, params.get("solver_testvectors") if params else None)
+                self._solver_cfg_built = dict(cfg) if isinstance(cfg, dict) else None
         else:
+            # a solver hierarchy the device setup built for its eigensolves stays in its slot, unused
+            self._have_solver_hier = False
             for eng in self.engines:
                 eng.set_solver(int(params.get("solver_restart", 24)) if params else 24, REF_HID)
 
@@ -409,8 +564,22 @@ class MG:
         self.coarsest_iters_tot += 1
         self.coarsest_iters_avg = self.coarsest_iters_tot / self.nr_calls
         if lvl == nlev - 1:
-            return eng.coarsest(REF_HID, np.asarray(b).reshape(-1))
+            return self._coarse_out(eng.coarsest(REF_HID, self._coarse_in(np.asarray(b).reshape(-1), lvl)), lvl)
         return eng.vcycle(self._hid_for(lvl), lvl, np.asarray(b).reshape(-1))
+
+    # ref_coarsest = "eo" (2-level hierarchies): the ENGINE holds the coarse dofs tile by tile, the host
+    # attributes and every vector that crosses these methods keep the reference's order
+    def _coarse_in(self, v, level):
+        if self.coarse_eo is None or level != 1:
+            return v
+        return np.ascontiguousarray(np.asarray(v)[..., self.coarse_eo[0]])
+
+    def _coarse_out(self, y, level):
+        if self.coarse_eo is None or level != 1:
+            return y
+        out = np.empty_like(y)
+        out[..., self.coarse_eo[0]] = y
+        return out
 
     def matvec(self, x):
         """multigrid.py:552-557: y = self.A * x on the GPU."""
@@ -444,7 +613,10 @@ class MG:
         nlev = len(self.ml.levels)
         skip = self.skip_level and lvl == 0
         v = np.asarray(v, dtype=np.complex128).reshape(-1)
-        vc = eng.restrict(REF_HID, lvl, v)
+        if self.coarse_eo is not None and lvl != 0:
+            raise Exception("ref_coarsest = 'eo' keeps the coarse level in tile order on the GPU: the difference "
+                            "operator is available at level 0 only in that mode")
+        vc = eng.restrict(REF_HID, lvl, v)       # (with coarse_eo: tile order in, tile order out below)
         lc = lvl + 1
         if skip:
             vc = eng.restrict(REF_HID, lvl + 1, vc)

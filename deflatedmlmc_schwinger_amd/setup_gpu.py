@@ -278,8 +278,9 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                 """weights of `degree` steps for the level operator (which 0) / its Schur complement (1)"""
                 if degree <= 0:
                     return np.zeros(0, dtype=np.complex128)
-                if on_device:
-                    # Arnoldi on the GPU (sw_setup_arnoldi): the host sees a (degree+1) x degree matrix
+                if on_device and degree <= 32:
+                    # Arnoldi on the GPU (sw_setup_arnoldi, at most 32 vectors): the host sees a
+                    # (degree+1) x degree matrix; longer polynomials are fitted through the C ABI below
                     return _hier.weights_from_hessenberg(eng.setup_arnoldi(hid, lv, which, degree))
                 proj = None
                 if which == 0 and cfg.get("smoother_target", "all") == "complement":
@@ -293,9 +294,10 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
                 if cfg.get("smoother", "richardson") == "richardson":
                     eo_here = lv in eo_levels
                     full_op = (lambda _lv=lv: _EngineOperator(eng, hid, _lv, sizes[_lv]))
-                    # (an even-odd smoothed level never runs its full-operator post-smoother)
+                    # (an even-odd smoothed level without pre-smoothing never runs its full-operator
+                    # post-smoother: vcycle_rich takes the even-odd one; with pre-smoothing it does run)
                     eng.set_smoother(hid, lv, fit(lv, 0, cyc[0], full_op),
-                                     fit(lv, 0, 0 if eo_here and on_device else cyc[1], full_op))
+                                     fit(lv, 0, 0 if eo_here and on_device and cyc[0] == 0 else cyc[1], full_op))
                     if lv == 0 and eo_here:
                         eng.set_eo_smoother(hid, 0, fit(0, 1, cyc[1],
                                                         lambda: _EngineSchur(eng, hid, L, mass)))
@@ -368,3 +370,94 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
             eng.set_eo_operator(hid, lv, 4, *_hier.dense_schur_inverse_blocks(ops))
     log.append({"seconds": {k: round(v, 3) for k, v in clock.items()}})
     return {"levels": sizes, "setup_log": log, "setup_s": time.time() - t0, "cfg": cfg}
+
+
+# ----------------------------------------------------------------------------------------------
+# device eigensolver: the host ARPACK + SuperLU calls of the setup, on the GPU
+# ----------------------------------------------------------------------------------------------
+def device_eigenpairs(eng, hid, level, k, tol, hermitian_g3=False, maxit=60, seed=11, start=None,
+                      log=None):
+    """The k eigenpairs nearest zero of A_level (hermitian_g3 = False: what eigs(A_l, k, sigma=0, tol)
+    returns at multigrid.py:174) or of Q = gamma_3 A_level (True: eigsh(Q, k, sigma=0, tol), utils.py:140),
+    by block subspace iteration with Rayleigh-Ritz on the engine:
+
+        V orthonormal [n][64];  W = Op^-1 V (the engine's batched multigrid solve: the shift-invert
+        operator ARPACK gets from SuperLU);  T = V^H W (fp64 MFMA Gram kernel);  Ritz pairs (theta, y) of T;
+        block residual E = W - V T on the device, M = E^H E: |Op^-1 x - theta x|^2 = y^H M y for x = V y
+        (formed from the small residual vectors themselves -- the difference W^H W - T^H T of two O(theta^2)
+        matrices would lose everything below 1e-8);  V <- W R^-1 (Cholesky-QR, twice).
+
+    Stops when the k Ritz pairs of largest |theta| all satisfy ARPACK's own shift-invert criterion
+    |Op^-1 x - theta x| <= tol |theta|.  The block width 64 (the engine's batch quantum: 64 solves cost what
+    one costs) makes the convergence factor |lambda_k / lambda_65| per step (0.13 for A, 0.16 for Q on
+    schwinger128).  The solves start loose and tighten with the residual (inexact inverse iteration).
+    Returns (lambda[k], X[n, k]) -- X columns of unit norm, orthonormal for the hermitian case --, and
+    appends per-step records to `log`."""
+    import scipy.linalg as sla
+    m = 64
+    if not 1 <= k <= m // 2:
+        raise Exception("device_eigenpairs: k = %d outside 1..%d" % (k, m // 2))
+    mode = 1 if hermitian_g3 else 0
+    eng.eig_begin(hid, level, seed)
+    try:
+        cur, nxt, tmp = 0, 1, 2
+        if start is not None:
+            eng.eig_load(cur, np.asarray(start))
+
+        def cholqr(src, dst):
+            """dst = src R^-1 with R^H R = src^H src"""
+            G = eng.eig_gram(src, src)
+            R = sla.cholesky(0.5 * (G + G.conj().T), lower=False)
+            eng.eig_rotate(src, sla.solve_triangular(R, np.eye(m, dtype=np.complex128), lower=False), dst)
+
+        # orthonormal start block
+        cholqr(cur, nxt)
+        cholqr(nxt, cur)
+        res_prev = 1.0
+        theta = Y = None
+        for it in range(maxit):
+            # the shift-invert solve; its tolerance follows the residual of the wanted pairs (inexact inverse
+            # iteration: an error of tol_s in b - A x moves the wanted Ritz vectors by about
+            # tol_s |lambda_k / lambda_1|, so two orders below the current residual is ample)
+            tol_s = min(1e-3, max(5e-13, 1e-2 * res_prev))
+            its = eng.eig_solve(cur, nxt, mode, tol_s)
+            T = eng.eig_gram(cur, nxt)
+            eng.eig_rotate(cur, T, tmp, sub=nxt)            # E = W - V T
+            M = eng.eig_gram(tmp, tmp)
+            if hermitian_g3:
+                theta, Y = np.linalg.eigh(0.5 * (T + T.conj().T))
+            else:
+                theta, Y = np.linalg.eig(T)
+                Y = Y / np.linalg.norm(Y, axis=0)[None, :]
+            # nearest zero = largest |theta|; of an (almost) degenerate modulus -- a complex-conjugate pair
+            # of A -- the member with the positive imaginary part first (ARPACK's choice is implementation-
+            # defined there, SURVEY section 3.4; this one is deterministic)
+            lam_all = 1.0 / theta
+            order = np.lexsort((-np.sign(np.round(lam_all.imag, 12)), np.round(np.abs(lam_all), 10)))
+            theta, Y = theta[order], Y[:, order]
+            yk = Y[:, :k]
+            r2 = np.einsum("ik,ij,jk->k", yk.conj(), M, yk).real
+            if not hermitian_g3:
+                # T y = theta y holds only to the accuracy of the dense eigensolver: add what it leaves
+                r2 = r2 + np.linalg.norm(T @ yk - yk * theta[None, :k], axis=0) ** 2
+            res = np.sqrt(np.maximum(r2, 0.0)) / np.abs(theta[:k])
+            res_prev = float(res.max())
+            if log is not None:
+                log.append({"step": it, "solve_tol": tol_s, "solve_iterations": its, "residual_max": res_prev})
+            if res_prev <= tol:
+                break
+            cholqr(nxt, tmp)
+            cholqr(tmp, cur)
+        else:
+            raise Exception("device_eigenpairs: %d wanted pairs not converged to %g in %d steps (residual %.2e)"
+                            % (k, tol, maxit, res_prev))
+        Yfull = np.zeros((m, m), dtype=np.complex128)
+        Yfull[:, :k] = Y[:, :k]
+        eng.eig_rotate(cur, Yfull, tmp)
+        X = eng.eig_fetch(tmp, k).T
+        lam = 1.0 / theta[:k]
+        if hermitian_g3:
+            lam = lam.real
+        return lam, np.ascontiguousarray(X)
+    finally:
+        eng.eig_end()

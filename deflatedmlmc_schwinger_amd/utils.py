@@ -161,15 +161,28 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
             cdir = _cache.cache_dir(params)
             ckey = _cache.matrix_key(A, {"k": nr_deflat_vctrs, "tol": tolx}) if cdir else None
             hit = _cache.load(cdir, "defl", ckey) if cdir else None
+            found = getattr(mg_solver, "_device_defl", {}).get((int(nr_deflat_vctrs), float(tolx)))
             if hit is not None:
                 Sy, Vx = hit["S"], hit["V"]
+            elif found is not None:
+                # computed on the GPU during MG.setup, while the host built the coarse levels
+                Sy, Vx = found
             else:
-                Q = (lev0.g3 * A).tocsc()                               # utils.py:137-140
-                # (with several ranks: rank 0's eigenpairs everywhere, see dist.compute_on_root)
-                Sy, Vx = _dist.default_comm().compute_on_root(
-                    lambda: eigsh(Q, k=nr_deflat_vctrs, which='LM', tol=tolx, sigma=0.0))
-                if cdir:
-                    _cache.save(cdir, "defl", ckey, {"S": Sy, "V": Vx})
+                device = (getattr(mg_solver, "_have_solver_hier", False) and nr_deflat_vctrs <= 32
+                          and getattr(mg_solver, "_solver_cfg_built", None) is not None
+                          and mg_solver._solver_cfg_built.get("setup") == "device"
+                          and params.get("setup_eigs", os.environ.get("SW_SETUP_EIGS", "device")) == "device")
+                if device:
+                    # eigsh(gamma_3 A, k, sigma=0) by block subspace iteration on the GPU (utils.py:137-140)
+                    Sy, Vx = _dist.default_comm().compute_on_root(
+                        lambda: mg_solver.device_eigenpairs(nr_deflat_vctrs, tolx, hermitian=True))
+                else:
+                    Q = (lev0.g3 * A).tocsc()                               # utils.py:137-140
+                    # (with several ranks: rank 0's eigenpairs everywhere, see dist.compute_on_root)
+                    Sy, Vx = _dist.default_comm().compute_on_root(
+                        lambda: eigsh(Q, k=nr_deflat_vctrs, which='LM', tol=tolx, sigma=0.0))
+            if hit is None and cdir:
+                _cache.save(cdir, "defl", ckey, {"S": Sy, "V": Vx})
     else:
         mg_solver.solve_tol = params['diff_lev_op_tol']                 # utils.py:142-143
         Sy, Vx = _dist.default_comm().compute_on_root(
@@ -183,6 +196,9 @@ def deflation_pre_computations(A, nr_deflat_vctrs, tolx, method, timer, params, 
             Ux = lev0.Pperm * Ux
     else:
         Vx = mg_solver.ml.levels[level_nr].g3 * Vx
+        if getattr(mg_solver, "coarse_eo", None) is not None and level_nr >= 1:
+            raise Exception("ref_coarsest = 'eo' keeps the coarse level in tile order on the GPU: MLMC-level "
+                            "deflation vectors at level %d are not supported in that mode" % level_nr)
         for eng in _engines(mg_solver):
             # the GPU probe body projects with these vectors (utils.py:260-266)
             eng.set_level_deflation(level_nr, np.asarray(Vx))

@@ -137,6 +137,11 @@ int sw_get_level_dense(sw_engine* h, int hid, int level, double* dense);
  * with partial pivoting by the engine's own kernels (k_gj_*; n <= 8192), then packed into MFMA block-row
  * form as sw_set_coarsest_inv would (multigrid.py:342-344: np.linalg.inv).  Fails on a singular operator. */
 int sw_setup_invert_coarsest(sw_engine* h, int hid);
+/* The dense coarsest inverse the engine holds (handed over by sw_set_coarsest_inv or formed on the device by
+ * sw_setup_invert_coarsest -- which also accepts a coarsest operator given as CSR, sw_set_csr) as a row-major
+ * complex128[n*n] host array: the reference's mg_solver.coarsest_inv (multigrid.py:342-344) for callers that
+ * read it (stoch_trace.py:428-435 traces it directly). */
+int sw_get_coarsest_inv(sw_engine* h, int hid, double* dense);
 /* The same one level up: the DENSE inverse of a block level's even-odd Schur complement (operator 0 of
  * sw_setup_eo_operators / sw_set_eo_operator; at most 8192 rows) formed on the device and installed as
  * that level's even-odd operator 4, with which the cycle solves the level exactly (option "eo_direct")
@@ -155,6 +160,28 @@ int sw_setup_level_inverse(sw_engine* h, int hid, int level);
  * complex128.  The host turns its harmonic Ritz values into the weights of sw_set_smoother /
  * sw_set_eo_smoother (the tuned stand-in for lgmres(maxiter=2), multigrid.py:393-394). */
 int sw_setup_arnoldi(sw_engine* h, int hid, int level, int which, int degree, uint64_t seed, double* Hout);
+/* ---- device eigensolver (SURVEY 8f-2 completed: the host ARPACK + SuperLU calls of the setup) -------------
+ * Block subspace iteration with the engine's own batched solve as the shift-invert operator: replaces
+ * eigs(A_l, k, sigma=0) (multigrid.py:174: test vectors) and eigsh(gamma_3 A, k, sigma=0) (utils.py:140:
+ * deflation vectors).  The engine does the O(n) work on blocks of 64 vectors held in three device buffers
+ * (index 0..2) on one finished (hid, level); the caller does the 64 x 64 dense algebra in between
+ * (Rayleigh-Ritz on V^H Op^-1 V, Cholesky-QR), see setup_gpu.device_eigenpairs.
+ *   sw_eig_begin   buffers on (hid, level), buffer 0 <- pseudo-random block
+ *   sw_eig_load    first ncols columns of buffer dst <- host vectors (reference order)
+ *   sw_eig_solve   buf_dst = Op^-1 buf_src, 64 right-hand sides to `tol`; mode 0: Op = A_level, mode 1:
+ *                  Op = gamma_3 A_level (gamma_3 = +1 / -1 on the first / second half of the reference order)
+ *   sw_eig_gram    out[64*64] = buf_a^H buf_b (fp64 MFMA, deterministic two-stage sum)
+ *   sw_eig_rotate  buf_dst = buf_src Y (sub < 0) or buf_sub - buf_src Y (the block residual W - V T), Y[64*64]
+ *                  row-major, dst != src
+ *   sw_eig_fetch   first k columns of buf_src as k host vectors in the reference order
+ *   sw_eig_end     release the buffers */
+int sw_eig_begin(sw_engine* h, int hid, int level, uint64_t seed);
+int sw_eig_load(sw_engine* h, int dst, int ncols, const double* X);
+int sw_eig_solve(sw_engine* h, int src, int dst, int mode, double tol, int maxiter, int32_t* iters_max);
+int sw_eig_gram(sw_engine* h, int a, int b, double* out);
+int sw_eig_rotate(sw_engine* h, int src, const double* Y, int dst, int sub);
+int sw_eig_fetch(sw_engine* h, int src, int k, double* out);
+int sw_eig_end(sw_engine* h);
 /* Mark the hierarchy complete (allocates level workspaces lazily). */
 int sw_hier_end(sw_engine* h, int hid);
 

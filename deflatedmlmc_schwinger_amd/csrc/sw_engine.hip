@@ -216,6 +216,12 @@ struct sw_engine {
   // passes instead of 3 nu
   bool eo_product = true;
   int gj_block = 32;      // panel width of the blocked Gauss-Jordan inverse (0: unblocked)
+  // fp64 even-odd kernels of the lattice level from LDS-staged halo tiles double-buffered by LDS-DMA, one
+  // persistent workgroup per CU (k_schur_tile; 0 off, 4 / 8 waves per workgroup): the launches without a b'
+  // operand (reduced operator, product-form factors) on full-lattice launches
+  int eo_tile = 0;
+  int eo_tile_dbg = 0;   // timing diagnostics of k_schur_tile (results are then wrong): 1 no prefetch, 2 no compute
+  int num_cus = 256;
   // levels that carry the dense inverse of their operator (sw_setup_level_inverse) are solved with it
   bool direct_small = true;
   bool lgmres_aug = true;   // reference-faithful smoother: LGMRES's augmentation vector in the second cycle
@@ -1282,6 +1288,24 @@ template <int MODE>
 static int launch_schur_step(sw_engine* h, swk::StencilArgs& a, const cplx* src, const cplx* bp, cplx* dst,
                              int nbp) {
   const int items = (a.nrows > 0 ? a.nrows : a.L) * (a.L / 2);
+  if (h->eo_tile > 0 && (MODE == 0 || MODE == 3) && a.nrows == 0 && a.L % 8 == 0) {
+    // LDS-staged halo tiles in rotated coordinates, double-buffered by LDS-DMA: one persistent workgroup per CU
+    constexpr int TM = (MODE == 0) ? 0 : 3;
+    const int tiles_v = a.L / 8, ntiles = (a.L / 4) * tiles_v;
+    swk::StencilArgs at = a;
+    at.row0 = h->eo_tile_dbg;      // (the tile kernel takes no row window: the field carries the diagnostic bits)
+    const int njobs = ntiles * (nbp / 64);
+    int grid = std::min(h->num_cus, njobs);
+    grid = std::max(8, (grid + 7) & ~7);
+    if (h->eo_tile == 8)
+      hipLaunchKernelGGL((swk::k_schur_tile<TM, 8>), dim3(grid), dim3(512), 0, h->stream, src, dst, at, tiles_v,
+                         ntiles, njobs);
+    else
+      hipLaunchKernelGGL((swk::k_schur_tile<TM, 4>), dim3(grid), dim3(256), 0, h->stream, src, dst, at, tiles_v,
+                         ntiles, njobs);
+    KLAUNCH_CHECK();
+    return 0;
+  }
   const int bpc = (items + SW_WAVES_PER_BLOCK - 1) / SW_WAVES_PER_BLOCK;
   hipLaunchKernelGGL((swk::k_schur_step<cplx, MODE>), dim3(bpc * (nbp / 64)), dim3(SW_BLOCK), 0, h->stream, src,
                      bp, dst, a, bpc);
@@ -2236,6 +2260,11 @@ int sw_create(sw_engine** out, int device_id) {
   }
   h->d_notconv = (int*)q;
   h->d_tick = (int*)q2;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+      h->num_cus = cus;
+  }
   *out = h;
   return 0;
 }
@@ -3593,6 +3622,15 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->gj_block = v;
     return 0;
   }
+  if (std::strcmp(name, "eo_tile_dbg") == 0) {
+    h->eo_tile_dbg = (int)value & 3;
+    return 0;
+  }
+  if (std::strcmp(name, "eo_tile") == 0) {
+    if (value != 0.0 && value != 4.0 && value != 8.0) return sw_fail(h, "eo_tile must be 0 (off), 4 or 8 waves");
+    h->eo_tile = (int)value;
+    return 0;
+  }
   if (std::strcmp(name, "eo_product") == 0) {
     h->eo_product = value != 0.0;
     return 0;
@@ -3794,7 +3832,7 @@ int sw_get_option(sw_engine* h, const char* name, double* value) {
       {"direct_small", (double)h->direct_small}, {"gram_cycle", (double)h->gram_cycle},
       {"lgmres_aug", (double)h->lgmres_aug}, {"verify", (double)h->verify}, {"lazy_sync", (double)h->lazy_sync},
       {"mfma_3m", (double)h->mfma_3m}, {"eo_skew_chunk", (double)h->eo_skew_chunk},
-      {"gj_block", (double)h->gj_block}, {"eo_product", (double)h->eo_product},
+      {"gj_block", (double)h->gj_block}, {"eo_product", (double)h->eo_product},       {"eo_tile", (double)h->eo_tile},
       {"mfma3_tiles", (double)h->mfma3_tiles}, {"mfma_ops", (double)h->mfma_ops},
       {"mfma_small_tiles", (double)h->mfma_small_tiles}, {"mfma_tiles", (double)h->mfma_tiles},
       {"direct_fallbacks", (double)h->direct_fallbacks}};

@@ -465,6 +465,260 @@ __global__ __launch_bounds__(SW_BLOCK) void k_schur_step(const C* __restrict__ X
 }
 
 // ------------------------------------------------------------------------------------------
+// One site of the Schur step as a function of its operands -- the 8 even neighbours at distance 2, the
+// site's own x, b' -- and of a LINK SOURCE, written in exactly the order of k_schur_step above (bit-identical
+// results): shared by the LDS-tiled persistent kernel below.  (A persistent REGISTER-pipelined form of
+// k_schur_step -- two workgroups per CU walking the items, the next item's 20 rows loading into a second
+// register set, 212-228 VGPRs -- was built on it, bit-identical, and measured 51 us against 35 per launch:
+// with two waves per SIMD only 160 KiB of loads are in flight per CU; profiles/r04_ab_sessions.txt, r04d.)
+// ------------------------------------------------------------------------------------------
+template <class C>
+struct SchurLoads {
+  SiteT<C> e20, em20, e02, e0m2, ePP, ePM, eMP, eMM;
+  C c0, c1, q0, q1;
+};
+
+// link sources: the 16 link values of one output site, m = 4 * (hop into o) + (position inside it)
+//   o = n + x: U1(xp,y) U2(xp,y) U2(xp,ym) U1(x,y)    o = n - x: U1(xmm,y) U2(xm,y) U2(xm,ym) U1(xm,y)
+//   o = n + y: U2(x,yp) U1(x,yp) U1(xm,yp) U2(x,y)    o = n - y: U2(x,ymm) U1(x,ym) U1(xm,ym) U2(x,ym)
+// packed tables of (dx + 2, dy + 2) in 2 bits each and of the direction bit (1: U2), indexed by m
+#define SW_LK_DX 0x9a9a54bfu   // dx + 2 for m = 0..15: 3 3 3 2 0 1 1 1 2 2 1 2 2 2 1 2
+#define SW_LK_DY 0x54bf9a9au   // dy + 2 for m = 0..15: 2 2 1 2 2 2 1 2 3 3 3 2 0 1 1 1
+#define SW_LK_U2 0x9966u       // U2 for m = 1,2,5,6,8,11,12,15
+
+// links from a 1-KiB LDS row this wave gathered by LDS-DMA: value (q, m) at slot q * 16 + m
+struct LdsLinks {
+  const cplx* row;   // + q * 16 already applied
+  template <int M>
+  __device__ __forceinline__ cplx get() const { return row[M]; }
+};
+
+template <class C, int MODE, class LK>
+__device__ __forceinline__ void schur_site_compute(const SchurLoads<C>& ld, C* __restrict__ Yc, int x, int y,
+                                                   const StencilArgsT<C>& a, const LK& lk) {
+  typedef SiteT<C> Site2;
+  typedef typename real_of<C>::type real;
+  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
+  Site2 z;
+  z.s0 = czero<C>();
+  z.s1 = z.s0;
+  Site2 t = z;                                          // o = n + x
+  hop_acc<0>(t, lk.template get<0>(), ld.e20);
+  hop_acc<2>(t, lk.template get<1>(), ld.ePP);
+  hop_acc<3>(t, lk.template get<2>(), ld.ePM);
+  Site2 acc = z;
+  hop_acc<0>(acc, lk.template get<3>(), t);
+  t = z;                                                // o = n - x
+  hop_acc<1>(t, lk.template get<4>(), ld.em20);
+  hop_acc<2>(t, lk.template get<5>(), ld.eMP);
+  hop_acc<3>(t, lk.template get<6>(), ld.eMM);
+  hop_acc<1>(acc, lk.template get<7>(), t);
+  t = z;                                                // o = n + y
+  hop_acc<2>(t, lk.template get<8>(), ld.e02);
+  hop_acc<0>(t, lk.template get<9>(), ld.ePP);
+  hop_acc<1>(t, lk.template get<10>(), ld.eMP);
+  hop_acc<2>(acc, lk.template get<11>(), t);
+  t = z;                                                // o = n - y
+  hop_acc<3>(t, lk.template get<12>(), ld.e0m2);
+  hop_acc<0>(t, lk.template get<13>(), ld.ePM);
+  hop_acc<1>(t, lk.template get<14>(), ld.eMM);
+  hop_acc<3>(acc, lk.template get<15>(), t);
+  const size_t r = eo_row(x, y, L, Vh);
+  const real d = a.diag, di = (real)1 / a.diag;
+  const C c0 = ld.c0, c1 = ld.c1, q0 = ld.q0, q1 = ld.q1;
+  const C z0 = czero<C>();
+  const C r0 = cschur(MODE == 4 ? z0 : q0, d, c0, di, acc.s0);
+  const C r1 = cschur(MODE == 4 ? z0 : q1, d, c1, di, acc.s1);
+  C o0, o1;
+  if (MODE == 0) {
+    o0 = csub(czero<C>(), r0);
+    o1 = csub(czero<C>(), r1);
+  } else if (MODE == 1) {
+    o0 = r0;
+    o1 = r1;
+  } else if (MODE == 4) {
+    C v0 = c0, v1 = c1;
+    cfma(v0, a.w, r0);
+    cfma(v1, a.w, r1);
+    o0 = q0;
+    o1 = q1;
+    cfma(o0, a.w2, v0);
+    cfma(o1, a.w2, v1);
+  } else {
+    o0 = c0;
+    o1 = c1;
+    cfma(o0, a.w, r0);
+    cfma(o1, a.w, r1);
+  }
+  Yc[r * nbp] = o0;
+  Yc[(r + 1) * nbp] = o1;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same step from an LDS-staged halo tile, double-buffered by LDS-DMA (engine option "eo_tile").
+// k_schur_step asks the L2 for 20 rows of 1 KiB per output site and chunk, 18 of them re-reads of rows
+// its neighbours also ask for: 694 MB through the L2 -> CU path per launch at 128^2 x 256 probes, the
+// ~70-77 GB/s per CU that path delivers for gathers, for 134-202 MB of unique bytes.  Here the even sites
+// are tiled in the ROTATED coordinates u = (x + y) / 2, v = (x - y) / 2 -- in which the eight even sites at
+// lattice distance 2 are exactly the 3 x 3 neighbourhood: (x,y) = ((u + v) mod L, (u - v) mod L) maps
+// u in [0, L), v in [0, L/2) one-to-one onto the even sites, and because the formula is periodic a halo
+// needs no wrap logic -- and a workgroup stages a 4 x 4 tile plus its halo ring (36 sites x 2 spins x 1 KiB
+// = 72 KiB) in LDS: 2.25 site loads per output site instead of 9.  One persistent workgroup per CU walks its
+// share of the (chunk, tile) jobs; while it computes tile k from one LDS buffer, the LDS-DMA loads of tile
+// k + 1 (global_load_lds_dwordx4: no VGPR destination, queued by the same waves before they start computing)
+// land in the other.  Synchronisation per tile: a COUNTED s_waitcnt vmcnt(stores of the previous tile) -- the
+// DMA loads of this tile were issued before those stores and VMEM operations retire in order, so they have
+// landed, while the stores stay in flight -- and one raw s_barrier (no __syncthreads: its fence would drain
+// the counter to zero).  XCD q's workgroups sweep the contiguous job band q, side by side, so the halo rows
+// neighbouring tiles share meet in that XCD's L2.  Arithmetic: schur_site_compute, bit-identical results.
+// MODE 0 / 3 (no b' operand).  L % 8 == 0.
+// ------------------------------------------------------------------------------------------
+#define SW_TILE_ROWS 72   // (4 + 2) x (4 + 2) sites x 2 spins
+
+__device__ __forceinline__ void uv_site(int uu, int vv, int L, int& x, int& y) {
+  x = uu + vv;
+  y = uu - vv;
+  if (x < 0) x += L;
+  if (x >= L) x -= L;
+  if (y < 0) y += L;
+  if (y >= L) y -= L;
+}
+
+template <int WAVES>
+__device__ __forceinline__ void schur_tile_issue(const cplx* __restrict__ X, unsigned lds_base, int u0, int v0,
+                                                 int wave, int lane, size_t col, int L, int Vh, int nbp) {
+  constexpr int RPW = SW_TILE_ROWS / WAVES;
+#pragma unroll
+  for (int t = 0; t < RPW; ++t) {
+    const int rho = wave * RPW + t;
+    const int st = rho >> 1, spin = rho & 1;
+    const int i = st / 6 - 1, j = st % 6 - 1;
+    int x, y;
+    uv_site(u0 + i, v0 + j, L, x, y);
+    const cplx* g = X + (eo_row(x, y, L, Vh) + spin) * nbp + col;
+    // global_load_lds_dwordx4 by hand (M0 = wave-uniform LDS byte address, written in the same statement): the
+    // builtin would work, but hipcc then puts s_waitcnt vmcnt(0) in front of the first ds_read that follows
+    // (its LDS-DMA alias bookkeeping), which serialises the prefetch with the compute it is meant to overlap
+    const unsigned dst = lds_base + (unsigned)rho * 1024u;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst));
+  }
+}
+
+__device__ __forceinline__ Site2 lds_site(const cplx* lds_buf, int i, int j, int lane) {
+  const int st = (i + 1) * 6 + (j + 1);
+  Site2 v;
+  v.s0 = lds_buf[(st * 2) * 64 + lane];
+  v.s1 = lds_buf[(st * 2 + 1) * 64 + lane];
+  return v;
+}
+
+// this wave's link gather for the tile at (u0, v0): lane q * 16 + m fetches link m of the wave's q-th output
+// site -- ONE LDS-DMA instruction with per-lane source addresses -- into the 1-KiB row at lds_dst
+template <int WAVES>
+__device__ __forceinline__ void schur_tile_links(const cplx* __restrict__ U1, const cplx* __restrict__ U2,
+                                                 unsigned lds_dst, int u0, int v0, int wave, int lane, int L) {
+  constexpr int SPW = 16 / WAVES;
+  const int q = lane >> 4, m = lane & 15;
+  const int sidx = wave * SPW + (q < SPW ? q : 0);
+  int x, y;
+  uv_site(u0 + (sidx >> 2), v0 + (sidx & 3), L, x, y);
+  int xx = x + (int)((SW_LK_DX >> (2 * m)) & 3u) - 2;
+  int yy = y + (int)((SW_LK_DY >> (2 * m)) & 3u) - 2;
+  if (xx < 0) xx += L;
+  if (xx >= L) xx -= L;
+  if (yy < 0) yy += L;
+  if (yy >= L) yy -= L;
+  const cplx* g = (((SW_LK_U2 >> m) & 1u) ? U2 : U1) + (size_t)yy * L + xx;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_dst));
+}
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void k_schur_tile(const cplx* __restrict__ X, cplx* __restrict__ Y,
+                                                              StencilArgs a, int tiles_v, int ntiles, int njobs) {
+  static_assert(MODE == 0 || MODE == 3, "tile kernel: modes without a b' operand");
+  // per buffer: 72 vector rows + one link row per wave
+  constexpr int BUF_ROWS = SW_TILE_ROWS + WAVES;
+  __shared__ cplx lds[2 * BUF_ROWS * 64];
+  constexpr int SPW = 16 / WAVES;            // output sites per wave and tile
+  constexpr int VM_PER_TILE = 2 * SPW;       // this wave's stores per tile (issued after its DMA loads)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7;
+  const int wgx = blockIdx.x >> 3, nwgx = gridDim.x >> 3;
+  const int band0 = (int)(((long long)njobs * xcd) >> 3);
+  const int band1 = (int)(((long long)njobs * (xcd + 1)) >> 3);
+  const int L = a.L, Vh = a.Vh, nbp = a.nbp;
+  int job = band0 + wgx;
+  if (job >= band1) return;
+  int cur = 0;
+  // LDS byte address of the tile buffers (the value of the address-space-3 pointer)
+  const unsigned lds0 = (unsigned)(unsigned long long)((__attribute__((address_space(3))) cplx*)lds);
+  {
+    const int chunk = job / ntiles, tile = job - chunk * ntiles;
+    const int u0 = (tile / tiles_v) * 4, v0 = (tile % tiles_v) * 4;
+    schur_tile_issue<WAVES>(X, lds0, u0, v0, wave, lane, (size_t)chunk * 64 + lane, L, Vh, nbp);
+    schur_tile_links<WAVES>(a.U1, a.U2, lds0 + (unsigned)(SW_TILE_ROWS + wave) * 1024u, u0, v0, wave, lane, L);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (;;) {
+    // tile `job` has landed in buffer `cur` (this wave's rows: counted wait below / prologue above); the barrier
+    // makes every wave's rows visible and says everybody is done reading the other buffer
+    __builtin_amdgcn_s_barrier();
+    const int chunk = job / ntiles, tile = job - chunk * ntiles;
+    const int u0 = (tile / tiles_v) * 4, v0 = (tile % tiles_v) * 4;
+    const size_t col = (size_t)chunk * 64 + lane;
+    const int nxt = job + nwgx;
+    const bool more = nxt < band1;
+    if (more && !(a.row0 & 1)) {      // (a.row0: diagnostic bits of option eo_tile_dbg -- 1: no prefetch, 2: no compute)
+      const int c2 = nxt / ntiles, t2 = nxt - c2 * ntiles;
+      const int u2 = (t2 / tiles_v) * 4, v2 = (t2 % tiles_v) * 4;
+      const unsigned b2 = lds0 + (unsigned)(cur ^ 1) * (BUF_ROWS * 1024u);
+      schur_tile_issue<WAVES>(X, b2, u2, v2, wave, lane, (size_t)c2 * 64 + lane, L, Vh, nbp);
+      schur_tile_links<WAVES>(a.U1, a.U2, b2 + (unsigned)(SW_TILE_ROWS + wave) * 1024u, u2, v2, wave, lane, L);
+    }
+    const cplx* buf = lds + (size_t)cur * BUF_ROWS * 64;
+    if (!(a.row0 & 2))
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+      const int sidx = wave * SPW + q;
+      const int i = sidx >> 2, j = sidx & 3;
+      SchurLoads<cplx> ld;
+      ld.e20 = lds_site(buf, i + 1, j + 1, lane);
+      ld.em20 = lds_site(buf, i - 1, j - 1, lane);
+      ld.e02 = lds_site(buf, i + 1, j - 1, lane);
+      ld.e0m2 = lds_site(buf, i - 1, j + 1, lane);
+      ld.ePP = lds_site(buf, i + 1, j, lane);
+      ld.ePM = lds_site(buf, i, j + 1, lane);
+      ld.eMP = lds_site(buf, i, j - 1, lane);
+      ld.eMM = lds_site(buf, i - 1, j, lane);
+      const Site2 own = lds_site(buf, i, j, lane);
+      ld.c0 = own.s0;
+      ld.c1 = own.s1;
+      ld.q0 = cmake(0.0, 0.0);
+      ld.q1 = ld.q0;
+      int x, y;
+      uv_site(u0 + i, v0 + j, L, x, y);
+      LdsLinks lk;
+      lk.row = buf + (size_t)(SW_TILE_ROWS + wave) * 64 + q * 16;
+      schur_site_compute<cplx, MODE>(ld, Y + col, x, y, a, lk);
+    }
+    if (!more) return;
+    // this wave's DMA loads of the next tile were issued BEFORE its 2 SPW stores above: all but the last
+    // 2 SPW VMEM operations retired = they have landed; its LDS reads of `cur` are complete as well
+    if (a.row0 & 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM_PER_TILE) : "memory");
+    job = nxt;
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Grouped-ELL operator: coarse operators A_l, prolongators P_l, restrictors R_l = P_l^H, the
 // dense coarsest inverse and the MLMC rhs maps.  G consecutive rows share one list of K column
 // indices (the dense-block structure of SURVEY 3.4); one wave = one row group x 64 probes, each

@@ -226,7 +226,10 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *                  on lattices beyond the Infinity Cache (-1 automatic, 0 off, > 0 strip height in rows; batches
  *                  too wide for admissible strips are walked 64-probe chunk by chunk, "eo_skew_chunk" (0)
  *                  forces that);
- *                  "eo_product" (1) the even-odd smoother of the reduced-system cycle in product form,
+ *                  "eo_tile" (0) the fp64 even-odd launches of the lattice level that carry no b' operand (reduced
+                  operator, product-form factors) from LDS-staged halo tiles in rotated coordinates, double-buffered
+                  by LDS-DMA, one persistent workgroup of 4 or 8 waves per CU (k_schur_tile); bit-identical results;
+                  "eo_product" (1) the even-odd smoother of the reduced-system cycle in product form,
  *                  x + beta prod_j (1 - u_j S)(b' - S x): the same polynomial as the steps
  *                  x <- x + w_k (b' - S x), 2 nu + 2 half-vector passes instead of 3 nu
  *   block levels:  "use_mfma" (1) fp64-MFMA block-row kernels vs grouped ELL; "mfma_3m" (1) three real

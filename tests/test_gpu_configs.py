@@ -477,6 +477,37 @@ def test_time_skewed_smoother_order_is_bit_identical():
         eng.close()
 
 
+def test_lds_tiled_schur_kernel_is_bit_identical():
+    """engine option eo_tile: the fp64 even-odd launches of the lattice level that carry no b' operand (the
+    reduced system's operator S x and the product-form factors v - u S v) from LDS-staged halo tiles in rotated
+    coordinates, double-buffered by LDS-DMA with the link values gathered into LDS alongside (k_schur_tile, 4 and
+    8 waves per persistent workgroup), against the one-wave-per-item k_schur_step: the same arithmetic per
+    site in the same order, so cycles and solves must be BIT-identical -- ragged batch (70 probes: two chunks),
+    256 probes (four chunks: eight jobs per CU), the 128^2 and a 16^2 lattice (tiles wrap around the torus)."""
+    A, tp, mg = _tuned128()
+    eng = mg.engine
+    n = A.shape[0]
+    try:
+        for nb, seed in ((70, 77), (256, 78)):
+            B = _rand((nb, n), seed)
+            ref = None
+            for tile in (0, 4, 8):
+                eng.set_option("eo_tile", tile)
+                eng.timers_reset()
+                Xc = eng.vcycle(SOLVER_HID, 0, B)
+                Xs, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+                Sx = eng.apply_dirac(SOLVER_HID, 0, B[:3])
+                if tile == 0:
+                    ref = (Xc, Xs, np.asarray(its), Sx)
+                    continue
+                assert np.array_equal(Xc, ref[0]), (nb, tile)
+                assert np.array_equal(Xs, ref[1]) and np.array_equal(np.asarray(its), ref[2]), (nb, tile)
+                assert np.array_equal(Sx, ref[3])
+    finally:
+        eng.set_option("eo_tile", 0)
+    eng.close()
+
+
 def test_product_form_smoother_matches_the_step_form():
     """engine option eo_product: the even-odd smoother of the reduced-system cycle as
     x + beta prod_j (1 - u_j S) (b' - S x) -- the factors read one half vector and write one, 2 nu + 2 passes

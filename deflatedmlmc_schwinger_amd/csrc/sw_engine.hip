@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdarg>
@@ -317,6 +318,9 @@ struct sw_engine {
   // took over
   std::vector<double> direct_relres;
   int64_t direct_fallbacks = 0;
+  // host time spent inside hipMalloc / hipFree, calls and bytes allocated since creation
+  double alloc_s = 0.0, alloc_bytes = 0.0;
+  int64_t alloc_calls = 0;
   // device eigensolver (sw_eig_*): three [n][64] block buffers on one (hierarchy, level), the gamma_3 signs
   // in that level's row order, the partial sums of the block Gram kernel
   cplx* eig_buf[3] = {nullptr, nullptr, nullptr};
@@ -341,9 +345,15 @@ static int sw_fail(sw_engine* h, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // memory helpers
 // ---------------------------------------------------------------------------------------------
+// hipMalloc / hipFree with their host time accumulated (option "alloc_seconds" etc.: the setup log splits its
+// phases into allocation time and the rest)
 static int dev_alloc(sw_engine* h, void** p, size_t bytes) {
   if (bytes == 0) bytes = 16;
+  const auto t0 = std::chrono::steady_clock::now();
   HIPCHK(hipMalloc(p, bytes));
+  h->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  h->alloc_calls++;
+  h->alloc_bytes += (double)bytes;
   h->allocs.push_back({*p, bytes});
   return 0;
 }
@@ -354,7 +364,9 @@ static int dev_free(sw_engine* h, void* p) {
       h->allocs.erase(h->allocs.begin() + i);
       break;
     }
+  const auto t0 = std::chrono::steady_clock::now();
   HIPCHK(hipFree(p));
+  h->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
 template <class T>
@@ -3835,7 +3847,9 @@ int sw_get_option(sw_engine* h, const char* name, double* value) {
       {"gj_block", (double)h->gj_block}, {"eo_product", (double)h->eo_product},       {"eo_tile", (double)h->eo_tile},
       {"mfma3_tiles", (double)h->mfma3_tiles}, {"mfma_ops", (double)h->mfma_ops},
       {"mfma_small_tiles", (double)h->mfma_small_tiles}, {"mfma_tiles", (double)h->mfma_tiles},
-      {"direct_fallbacks", (double)h->direct_fallbacks}};
+      {"direct_fallbacks", (double)h->direct_fallbacks}, {"alloc_seconds", h->alloc_s},
+      {"alloc_calls", (double)h->alloc_calls}, {"alloc_gbytes", h->alloc_bytes * 1e-9},
+      {"eo_tile_dbg", (double)h->eo_tile_dbg}};
   for (const Ent& e : tab)
     if (std::strcmp(name, e.name) == 0) {
       *value = e.v;

@@ -688,9 +688,13 @@ TUNED_SOLVER_CFG_128 = {
     "cycle": [(0, 8, 0), (0, 10, 0)],
     "smoother": "richardson",
     "eo_levels": [0, 1],        # levels smoothed on their even-odd Schur complement (half vectors)
-    "restart": 3,               # the cycle is strong enough that GMRES(3) keeps the iteration count; with the
-                                # Gram-form cycles of round 3, 2 / 3 / 4: 32.3k / 35.1k / 35.7k probe-samples/s -- 3 kept:
-                                # restart 4 leaves the normal equations two orders less conditioning margin
+    "restart": 4,               # the cycle is strong enough that short restarts keep the iteration count; Gram-form
+                                # cycles, 2 / 3 / 4: 32.3k / 35.1k / 35.7k probe-samples/s in round 3; round 4, strict
+                                # parity mode (12 iterations = three cycles of four): 34.6k -> 35.1k, at the
+                                # reference's stopping point 36.9k -> 37.6k (profiles/r04_ab_sessions.txt, r04g).  The
+                                # normal equations of a cycle of four are conditioned ~1e8: y to ~1e-8 relative,
+                                # ample for a cycle that reduces the residual by ~1e-5 and always ends on the TRUE
+                                # residual; a pivot below 1e-13 of its diagonal truncates the cycle (fg_gram_col)
     "setup": "device",
     # device setup: three RELAXATION sweeps per new level (setup_tol = 0: a fixed 32 unpreconditioned
     # GMRES(restart) steps each that damp the rough components of the random start vectors -- relaxation by

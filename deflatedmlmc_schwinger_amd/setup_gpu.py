@@ -229,15 +229,21 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
     clock = {"geometry": 0.0, "testvectors": 0.0, "transfer+galerkin": 0.0, "coarsest_inverse": 0.0,
              "smoother_polynomials": 0.0}
 
+    # every phase: wall seconds and, of those, the host seconds inside hipMalloc / hipFree (the engine counts
+    # them: option "alloc_seconds"); the difference is kernels + host round trips
+    alloc_clock = {}
+
     class _timed:
         def __init__(self, key):
             self.key = key
 
         def __enter__(self):
             self.t = time.time()
+            self.a = eng.get_option("alloc_seconds")
 
         def __exit__(self, *exc):
             clock[self.key] += time.time() - self.t
+            alloc_clock[self.key] = alloc_clock.get(self.key, 0.0) + eng.get_option("alloc_seconds") - self.a
 
     Lf, hd = L, 1
     with _timed("geometry"):
@@ -368,7 +374,9 @@ def device_solver_hierarchy(eng, lat, cfg, hid):
             if ops is None:
                 raise Exception("direct_levels: level %d has no 5-point block structure" % lv)
             eng.set_eo_operator(hid, lv, 4, *_hier.dense_schur_inverse_blocks(ops))
-    log.append({"seconds": {k: round(v, 3) for k, v in clock.items()}})
+    log.append({"seconds": {k: round(v, 3) for k, v in clock.items()},
+                "of_which_hipMalloc_hipFree": {k: round(v, 3) for k, v in alloc_clock.items()},
+                "allocated_GB_so_far": round(eng.get_option("alloc_gbytes"), 2)})
     return {"levels": sizes, "setup_log": log, "setup_s": time.time() - t0, "cfg": cfg}
 
 

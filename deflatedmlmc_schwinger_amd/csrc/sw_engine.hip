@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -80,6 +81,9 @@ struct EllOp {
   int* bsr_tmap = nullptr;   // optional: row tile -> tile of the output vector (subset operators)
   int bsr_RT = 0;            // row tiles when != nrows / 16 (subset operators)
   bool bsr_diag_last = false;   // the last four k-steps of every row tile are its own X rows (check_diag_last)
+  // dense operator whose row tiles all list the same columns in the same order (kcol rows identical): the
+  // LDS-staged dense kernel (k_dense_mfma3_lds) shares the X rows of a k-step between row tiles
+  bool dense_uniform = false;
   // complex64 mirrors of the value arrays (same index arrays), made on demand for the
   // single-precision preconditioner (option precond_f32)
   cplxf* vals32 = nullptr;
@@ -221,6 +225,10 @@ struct sw_engine {
   // persistent workgroup per CU (k_schur_tile; 0 off, 4 / 8 waves per workgroup): the launches without a b'
   // operand (reduced operator, product-form factors) on full-lattice launches
   int eo_tile = 0;
+  // dense operators (coarsest inverse, dense Schur inverse of a direct level, direct inverse of a small level)
+  // through the LDS-staged three-product kernel k_dense_mfma3_lds (A/B switch)
+  int dense_lds = 4;     // row tiles per workgroup (2 or 4); 0: k_bsr_mfma3.  2048^2 on 256 probes, per launch:
+                         // k_bsr_mfma3 142 us, 2 tiles 157, 4 tiles 135 (profiles/r04_ab_sessions.txt, r04j)
   int eo_tile_dbg = 0;   // timing diagnostics of k_schur_tile (results are then wrong): 1 no prefetch, 2 no compute
   int num_cus = 256;
   // levels that carry the dense inverse of their operator (sw_setup_level_inverse) are solved with it
@@ -320,7 +328,7 @@ struct sw_engine {
   int64_t direct_fallbacks = 0;
   // host time spent inside hipMalloc / hipFree, calls and bytes allocated since creation
   double alloc_s = 0.0, alloc_bytes = 0.0;
-  int64_t alloc_calls = 0;
+  int64_t alloc_calls = 0, pool_hits = 0;
   // device eigensolver (sw_eig_*): three [n][64] block buffers on one (hierarchy, level), the gamma_3 signs
   // in that level's row order, the partial sums of the block Gram kernel
   cplx* eig_buf[3] = {nullptr, nullptr, nullptr};
@@ -346,26 +354,89 @@ static int sw_fail(sw_engine* h, const char* fmt, ...) {
 // memory helpers
 // ---------------------------------------------------------------------------------------------
 // hipMalloc / hipFree with their host time accumulated (option "alloc_seconds" etc.: the setup log splits its
-// phases into allocation time and the rest)
+// phases into allocation time and the rest).  Large blocks are PARKED instead of freed and handed out again:
+// the device setup allocates and frees multi-GB scratch per level (11.8 GB for one Arnoldi run on the 1024^2
+// lattice), and in a process that has already moved ~100 GB through the allocator those calls were measured at
+// 2.5-3.4 s per setup where a fresh process needs 0.02 s (profiles/r04_ab_sessions.txt, r04h: the cause of the
+// driver-observed 2.4x slower 1024^2 setup of round 3).  The pool is per process (engines come and go), capped
+// (SW_POOL_GB, default 48; 0 disables), and a block is parked only after the freeing engine's streams have
+// drained (hipFree's implicit synchronisation is what made reuse by another stream safe before).
+namespace {
+struct ParkedBlock {
+  void* p;
+  size_t bytes;
+  int device;
+};
+std::mutex g_pool_mu;
+std::vector<ParkedBlock> g_pool;
+size_t g_pool_bytes = 0;
+const size_t kPoolMinBlock = (size_t)32 << 20;
+size_t pool_cap() {
+  static const size_t cap = [] {
+    const char* e = std::getenv("SW_POOL_GB");
+    const double gb = e ? std::atof(e) : 48.0;
+    return gb > 0.0 ? (size_t)(gb * 1073741824.0) : (size_t)0;
+  }();
+  return cap;
+}
+}  // namespace
+
 static int dev_alloc(sw_engine* h, void** p, size_t bytes) {
   if (bytes == 0) bytes = 16;
   const auto t0 = std::chrono::steady_clock::now();
-  HIPCHK(hipMalloc(p, bytes));
+  *p = nullptr;
+  size_t got = bytes;
+  if (bytes >= kPoolMinBlock && pool_cap() > 0) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i].device == h->device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 4 &&
+          (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
+        best = (int)i;
+    if (best >= 0) {
+      *p = g_pool[best].p;
+      got = g_pool[best].bytes;
+      g_pool_bytes -= got;
+      g_pool.erase(g_pool.begin() + best);
+      h->pool_hits++;
+    }
+  }
+  if (!*p) HIPCHK(hipMalloc(p, bytes));
   h->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   h->alloc_calls++;
   h->alloc_bytes += (double)bytes;
-  h->allocs.push_back({*p, bytes});
+  h->allocs.push_back({*p, got});
   return 0;
 }
 static int dev_free(sw_engine* h, void* p) {
   if (!p) return 0;
+  size_t bytes = 0;
   for (size_t i = 0; i < h->allocs.size(); ++i)
     if (h->allocs[i].first == p) {
+      bytes = h->allocs[i].second;
       h->allocs.erase(h->allocs.begin() + i);
       break;
     }
   const auto t0 = std::chrono::steady_clock::now();
-  HIPCHK(hipFree(p));
+  if (bytes >= kPoolMinBlock && pool_cap() > 0) {
+    // nothing of this engine may still be using the block when another stream gets it
+    if (h->stream) HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->gen_stream) HIPCHK(hipStreamSynchronize(h->gen_stream));
+    std::vector<void*> evict;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      g_pool.push_back({p, bytes, h->device});
+      g_pool_bytes += bytes;
+      while (g_pool_bytes > pool_cap() && !g_pool.empty()) {     // oldest first
+        evict.push_back(g_pool.front().p);
+        g_pool_bytes -= g_pool.front().bytes;
+        g_pool.erase(g_pool.begin());
+      }
+    }
+    for (void* q : evict) HIPCHK(hipFree(q));
+  } else {
+    HIPCHK(hipFree(p));
+  }
   h->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
@@ -550,6 +621,23 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   LaunchScope ls(h, cls);
   // 16 rows x 4 columns x nbp probes x 8 flops per complex multiply-add, per (tile, k-step)
   if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
+  if (h->mfma_3m && h->dense_lds > 0 && cat == T_COARSEST && mode == 0 && op.dense_uniform &&
+      RT % h->dense_lds == 0 && op.bsr_KS % (SW_DL_KB * SW_DL_DEPTH) == 0 && op.bsr_KS >= 2 * SW_DL_KB * SW_DL_DEPTH &&
+      (nbp & 31) == 0 && X != Y) {
+    // dense operator: operands shared through LDS (register-staged, double-buffered), one workgroup per
+    // (16 dense_lds)-row x 32-probe block -- 1 KiB (0.75 KiB) per wave and k-step through the L2 -> CU path
+    // instead of 2
+    if (h->dense_lds == 4)
+      hipLaunchKernelGGL((swk::k_dense_mfma3_lds<4>), dim3((RT / 4) * (nbp / 32)), dim3(512), 0, h->stream,
+                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, Y, nbp,
+                         (const int*)op.bsr_tmap);
+    else
+      hipLaunchKernelGGL((swk::k_dense_mfma3_lds<2>), dim3((RT / 2) * (nbp / 32)), dim3(256), 0, h->stream,
+                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, Y, nbp,
+                         (const int*)op.bsr_tmap);
+    KLAUNCH_CHECK();
+    return 0;
+  }
   if (h->mfma_3m) {
     // three real products per complex one (k_bsr_mfma3): tiles of 16 probes per wave
     // Measured (gpurun_out r03d): one tile of 16 probes per wave wins wherever it was compared -- the
@@ -2241,6 +2329,21 @@ int sw_device_count(void) {
 
 const char* sw_last_error(sw_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// Return the device memory the process-wide block pool has parked (dev_free) to the driver.
+int sw_pool_trim(void) {
+  std::vector<ParkedBlock> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    blocks.swap(g_pool);
+    g_pool_bytes = 0;
+  }
+  int rc = 0;
+  for (auto& b : blocks) {
+    if (hipSetDevice(b.device) != hipSuccess || hipFree(b.p) != hipSuccess) rc = 1;
+  }
+  return rc;
+}
+
 int sw_create(sw_engine** out, int device_id) {
   if (!out) return 1;
   *out = nullptr;
@@ -2289,7 +2392,7 @@ int sw_destroy(sw_engine* h) {
   for (auto& sl : h->slots)
     if (sl.ready) (void)hipEventDestroy(sl.ready);
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
-  for (auto& a : h->allocs) (void)hipFree(a.first);
+  while (!h->allocs.empty()) (void)dev_free(h, h->allocs.back().first);     // (large blocks: parked for the next engine)
   for (auto& r : h->recs) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
@@ -2504,6 +2607,7 @@ int sw_set_coarsest_inv(sw_engine* h, int hid, int n, const double* dense) {
     SWCHK(upload(h, &op.bsr_kcol, kcol.data(), kcol.size()));
     SWCHK(upload(h, (std::complex<double>**)&op.bsr_vals, pk.data(), pk.size()));
     op.bsr_KS = KS;
+    op.dense_uniform = true;
   }
   return 0;
 }
@@ -2862,6 +2966,7 @@ int sw_setup_invert_coarsest(sw_engine* h, int hid) {
   }
   op.bsr_KS = KS;
   op.set = true;
+  op.dense_uniform = true;     // k_dense_to_bsr: the column list depends on the k-step only
   SWCHK(stream_sync(h));
   SWCHK(dev_free(h, D));
   return 0;
@@ -2971,6 +3076,7 @@ int sw_setup_direct_level(sw_engine* h, int hid, int level) {
     KLAUNCH_CHECK();
   }
   op.set = true;
+  op.dense_uniform = true;     // k_dense_to_bsr: the column list depends on the k-step only
   SWCHK(stream_sync(h));
   SWCHK(dev_free(h, D));
   SWCHK(dev_free(h, d_rank));
@@ -3036,6 +3142,7 @@ int sw_setup_level_inverse(sw_engine* h, int hid, int level) {
   }
   op.bsr_KS = KS;
   op.set = true;
+  op.dense_uniform = true;     // k_dense_to_bsr: the column list depends on the k-step only
   H.f32_valid = false;
   SWCHK(stream_sync(h));
   SWCHK(dev_free(h, D));
@@ -3191,6 +3298,12 @@ int sw_set_eo_operator(sw_engine* h, int hid, int level, int which, int RT, int 
                (size_t)RT * KS * 64));
   op.set = true;
   check_diag_last(op, kcol, tmap);
+  if (which == 4) {
+    // a dense inverse: every row tile lists the same columns in the same order?
+    bool uni = true;
+    for (int r = 1; r < RT && uni; ++r) uni = std::memcmp(kcol, kcol + (size_t)r * KS, sizeof(int32_t) * KS) == 0;
+    op.dense_uniform = uni;
+  }
   return 0;
 }
 
@@ -3634,6 +3747,11 @@ int sw_set_option(sw_engine* h, const char* name, double value) {
     h->gj_block = v;
     return 0;
   }
+  if (std::strcmp(name, "dense_lds") == 0) {
+    if (value != 0.0 && value != 1.0 && value != 2.0 && value != 4.0) return sw_fail(h, "dense_lds must be 0, 2 or 4");
+    h->dense_lds = value == 1.0 ? 2 : (int)value;
+    return 0;
+  }
   if (std::strcmp(name, "eo_tile_dbg") == 0) {
     h->eo_tile_dbg = (int)value & 3;
     return 0;
@@ -3844,11 +3962,12 @@ int sw_get_option(sw_engine* h, const char* name, double* value) {
       {"direct_small", (double)h->direct_small}, {"gram_cycle", (double)h->gram_cycle},
       {"lgmres_aug", (double)h->lgmres_aug}, {"verify", (double)h->verify}, {"lazy_sync", (double)h->lazy_sync},
       {"mfma_3m", (double)h->mfma_3m}, {"eo_skew_chunk", (double)h->eo_skew_chunk},
-      {"gj_block", (double)h->gj_block}, {"eo_product", (double)h->eo_product},       {"eo_tile", (double)h->eo_tile},
+      {"gj_block", (double)h->gj_block}, {"eo_product", (double)h->eo_product},       {"eo_tile", (double)h->eo_tile}, {"dense_lds", (double)h->dense_lds},
       {"mfma3_tiles", (double)h->mfma3_tiles}, {"mfma_ops", (double)h->mfma_ops},
       {"mfma_small_tiles", (double)h->mfma_small_tiles}, {"mfma_tiles", (double)h->mfma_tiles},
       {"direct_fallbacks", (double)h->direct_fallbacks}, {"alloc_seconds", h->alloc_s},
       {"alloc_calls", (double)h->alloc_calls}, {"alloc_gbytes", h->alloc_bytes * 1e-9},
+      {"pool_hits", (double)h->pool_hits},
       {"eo_tile_dbg", (double)h->eo_tile_dbg}};
   for (const Ent& e : tab)
     if (std::strcmp(name, e.name) == 0) {

@@ -99,6 +99,7 @@ def load_library():
     sig("sw_set_solver", i32, vp, i32, i32)
     sig("sw_set_option", i32, vp, C.c_char_p, dbl)
     sig("sw_get_option", i32, vp, C.c_char_p, P(dbl))
+    sig("sw_pool_trim", i32)
     sig("sw_get_coarsest_inv", i32, vp, i32, vp)
     sig("sw_eig_begin", i32, vp, i32, i32, C.c_uint64)
     sig("sw_eig_load", i32, vp, i32, i32, vp)
@@ -156,7 +157,7 @@ EXPORTED_SYMBOLS = (
     "sw_set_smoother", "sw_set_gmres_smoother", "sw_set_eo_smoother", "sw_set_eo_operator", "sw_setup_eo_operators", "sw_apply_eo_operator",
     "sw_get_level_bsr", "sw_setup_testvectors", "sw_setup_transfer",
     "sw_setup_galerkin", "sw_get_level_dense", "sw_setup_invert_coarsest", "sw_setup_direct_level", "sw_setup_level_inverse", "sw_setup_arnoldi", "sw_hier_end", "sw_set_deflation", "sw_set_level_deflation", "sw_set_perm", "sw_set_rhsmap", "sw_set_solver", "sw_set_option", "sw_get_option",
-    "sw_get_coarsest_inv", "sw_eig_begin", "sw_eig_load", "sw_eig_solve", "sw_eig_gram", "sw_eig_rotate", "sw_eig_fetch", "sw_eig_end",
+    "sw_pool_trim", "sw_get_coarsest_inv", "sw_eig_begin", "sw_eig_load", "sw_eig_solve", "sw_eig_gram", "sw_eig_rotate", "sw_eig_fetch", "sw_eig_end",
     "sw_apply_dirac", "sw_restrict", "sw_prolong", "sw_coarsest", "sw_vcycle", "sw_solve",
     "sw_hutch_batch", "sw_probes_upload", "sw_probes_upload_slot", "sw_probes_select",
     "sw_kernel_stats", "sw_kernel_work", "sw_hutch_run", "sw_sync", "sw_hutch_fetch",
@@ -167,6 +168,11 @@ EXPORTED_SYMBOLS = (
     "sw_mt_jump_poly", "sw_mt_window_jump",
     "sw_probes_stream_set", "sw_probes_generate", "sw_probes_fetch",
 )
+
+
+def pool_trim():
+    """Release the device memory the engines' process-wide block pool has parked."""
+    return load_library().sw_pool_trim()
 
 
 def device_count():

@@ -41,6 +41,10 @@ int sw_create(sw_engine** out, int device_id);
 int sw_destroy(sw_engine* h);
 const char* sw_last_error(sw_engine* h);          /* h may be NULL: last create() error */
 int sw_device_count(void);                         /* 0 when no GPU is visible            */
+/* Device blocks of 32 MB and more that an engine frees (setup scratch, workspaces, everything at sw_destroy)
+ * are parked in a process-wide pool and handed out again instead of going back to the driver (cap SW_POOL_GB,
+ * default 48 GB; 0 disables): sw_pool_trim() releases what is parked. */
+int sw_pool_trim(void);
 const char* sw_version(void);
 
 /* ---- operands (products of MG.setup, multigrid.py:100-345, and matrix.py:14-31) ------ */
@@ -238,6 +242,9 @@ int sw_set_solver(sw_engine* h, int restart, int solver_hid);
  *                  "mfma_small_tiles", "bsr_stages" / "dense_stages" (register pipeline depth), "bsr_nt",
  *                  "bsr_xreg", "bsr_sub", "dense_map", "ell_order"; complex64 twins "f32_tiles",
  *                  "f32_stages", "f32_dense_stages", "f32_splitk", "f32_pairs"
+ *                  "dense_lds" (4) dense operators (coarsest inverse, dense Schur inverse of a directly solved
+ *                  level, direct inverse of a small level) through k_dense_mfma3_lds: operands shared through LDS
+ *                  (register-staged, double-buffered), 2 or 4 row tiles x 2 probe tiles per workgroup (0: k_bsr_mfma3)
  *   setup:         "gj_block" (32) panel width of the blocked Gauss-Jordan inverse (0: unblocked)
  *   sw_bench_dirac: "bench_mode" (0 Y=AX, 1 residual, 2 smoother step), "bench_what" (operator / R / P /
  *                  coarsest) */

@@ -508,6 +508,38 @@ def test_lds_tiled_schur_kernel_is_bit_identical():
     eng.close()
 
 
+def test_lds_staged_dense_kernel_is_bit_identical():
+    """engine option dense_lds (default on): dense operators -- the dense Schur inverse of the directly solved
+    4096-row level (2048^2, through tmap / kcol: the even sites' tiles), the 1024^2 coarsest inverse -- applied by
+    k_dense_mfma3_lds (operands staged through LDS by a ring of LDS-DMA fills, 64-row x 32-probe blocks per
+    workgroup) against k_bsr_mfma3 (fragments straight from L2): the same three-product arithmetic over the same
+    k-steps in the same order, so cycles, coarsest applications and solves must be BIT-identical; 70 probes (two
+    64-probe chunks, i.e. four probe pairs) and 256."""
+    A, tp, mg = _tuned128()
+    eng = mg.engine
+    n = A.shape[0]
+    nc = mg.solver_info["levels"][-1]
+    try:
+        for nb, seed in ((70, 91), (256, 92)):
+            B = _rand((nb, n), seed)
+            C = _rand((nb, nc), seed + 10)
+            ref = None
+            for on in (0, 1):
+                eng.set_option("dense_lds", on)
+                Xc = eng.vcycle(SOLVER_HID, 0, B)
+                Yc = eng.coarsest(SOLVER_HID, C)
+                Xs, its, rr = eng.solve(SOLVER_HID, 0, B, 1e-12, 200)
+                if ref is None:
+                    ref = (Xc, Yc, Xs, np.asarray(its))
+                    continue
+                assert np.array_equal(Yc, ref[1]), nb
+                assert np.array_equal(Xc, ref[0]), nb
+                assert np.array_equal(Xs, ref[2]) and np.array_equal(np.asarray(its), ref[3]), nb
+    finally:
+        eng.set_option("dense_lds", 1)
+    eng.close()
+
+
 def test_product_form_smoother_matches_the_step_form():
     """engine option eo_product: the even-odd smoother of the reduced-system cycle as
     x + beta prod_j (1 - u_j S) (b' - S x) -- the factors read one half vector and write one, 2 nu + 2 passes

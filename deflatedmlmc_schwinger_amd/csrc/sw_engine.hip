@@ -385,12 +385,20 @@ static int dev_alloc(sw_engine* h, void** p, size_t bytes) {
   if (bytes == 0) bytes = 16;
   const auto t0 = std::chrono::steady_clock::now();
   *p = nullptr;
+  if (bytes >= kPoolMinBlock && pool_cap() > 0) {
+    // size classes of 1/8 octave (at most 12.5 % over the request), so that workspaces of similar shapes --
+    // Krylov bases of m or m + 1 vectors, the Arnoldi basis, probing blocks -- meet in the pool
+    size_t top = (size_t)1 << 25;
+    while ((top << 1) <= bytes) top <<= 1;
+    const size_t step = top >> 3;
+    bytes = ((bytes + step - 1) / step) * step;
+  }
   size_t got = bytes;
   if (bytes >= kPoolMinBlock && pool_cap() > 0) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     int best = -1;
     for (size_t i = 0; i < g_pool.size(); ++i)
-      if (g_pool[i].device == h->device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 4 &&
+      if (g_pool[i].device == h->device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes &&
           (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
         best = (int)i;
     if (best >= 0) {

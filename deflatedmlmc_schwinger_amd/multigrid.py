@@ -136,6 +136,12 @@ class MG:
                 ckey = None
         self._cache_dir = cdir
         t0 = time.time()
+        if self._device_setup_wanted(params) and params.get("defer_coarse_levels"):
+            # plain / deflated Hutchinson flows never touch the coarse levels of the reference hierarchy on the
+            # GPU: build them on a host thread WHILE the probes run and join at the end (finish_setup)
+            self._deferred_reference_hierarchy(dof, aggrs, max_levels, acc_eigvs, params, tv, ckey)
+            self.setup_log["reference_hierarchy_s"] = round(time.time() - t0, 4)
+            return
         if self._device_setup_wanted(params):
             ml, cinv, used = self._device_reference_hierarchy(dof, aggrs, max_levels, acc_eigvs, params, tv)
         else:
@@ -201,6 +207,88 @@ class MG:
         if not self._have_solver_hier:
             raise EngineError("the device eigensolver needs the level-0 solver hierarchy")
         return setup_gpu.device_eigenpairs(self.engine, SOLVER_HID, 0, k, tol, hermitian_g3=hermitian, log=log)
+
+    def _deferred_reference_hierarchy(self, dof, aggrs, max_levels, acc_eigvs, params, tv, ckey):
+        """Device setup for flows that use level 0 only (stoch_trace.hutchinson): engines, solver hierarchy,
+        level-0 test vectors and deflation vectors on the GPU as in _device_reference_hierarchy; the host part
+        (P_l, A_{l+1}, the small levels' ARPACK) starts on a thread and is NOT waited for -- finish_setup() joins
+        it when somebody needs the coarse levels (the flow's work model reads their nnz at the very end).  The
+        engine's reference hierarchy keeps the lattice level only."""
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.time()
+        self._prepare_device(params)
+        self.setup_log["solver_hierarchy_s"] = round(time.time() - t0, 4)
+        comm = _dist.default_comm()
+        tolx = 1.0e-3 if acc_eigvs == "low" else 1.0e-9
+        kd = int(params.get("nr_deflat_vctrs", 0) or 0)
+        tol_d = params.get("defl_eigvs_tol_Hutch", 1.0e-9)
+        want_defl = kd > 0 and params.get("deflation_eigenpairs") is None and kd <= 32
+        if want_defl and self._cache_dir:
+            dkey = _cache.matrix_key(self._A0, {"k": kd, "tol": tol_d})
+            want_defl = _cache.load(self._cache_dir, "defl", dkey) is None
+
+        def root_job():
+            tv0 = None
+            if tv is None:
+                log = []
+                t1 = time.time()
+                _, tv0 = self.device_eigenpairs(int(dof[1] / 2), tolx, log=log)
+                self.setup_log["eigs_level0"] = {"seconds": round(time.time() - t1, 4), "steps": log}
+            return tv0
+        tv0 = comm.compute_on_root(root_job)
+        tvs = tv if tv is not None else [tv0]
+        self._pending_pool = ThreadPoolExecutor(max_workers=1)
+        self._pending = self._pending_pool.submit(_hier.reference_hierarchy, self._A0, dof, aggrs, max_levels,
+                                                  acc_eigvs, params, tvs, None, False)
+        self._pending_ckey = ckey
+        if want_defl:
+            dlog = []
+            t1 = time.time()
+            defl = comm.compute_on_root(lambda: self.device_eigenpairs(kd, tol_d, hermitian=True, log=dlog))
+            self.setup_log["eigsh_deflation"] = {"seconds": round(time.time() - t1, 4), "steps": dlog}
+            self._device_defl[(kd, float(tol_d))] = defl
+        # level 0 as the estimators read it (multigrid.py:130-155), the rest arrives with finish_setup()
+        lev = self.ml.levels[0]
+        n = self._A0.shape[0]
+        sign = np.ones(n)
+        sign[n // 2:] = -1.0
+        lev.g3 = sp.diags([sign], [0])
+        if params["use_permuted"]:
+            shift0 = params["latt_dims"][0] * 2 * params["x_displacement"]
+            lev.perm_shift = shift0
+            lev.Pperm = _hier.shift_operator(n, shift0)
+            lev.Bblock_perm = sp.identity(n, dtype=np.complex128, format="csr")
+            for eng in self.engines:
+                eng.set_perm(0, int(shift0))
+        self.total_levels = max_levels
+        self.A = lev.A
+        self._cinv = None
+        if params.get("stop_factor") is not None:
+            for eng in self.engines:
+                eng.set_option("stop_factor", float(params["stop_factor"]))
+
+    def finish_setup(self):
+        """Join the host thread that builds the coarse levels of a deferred setup (no-op otherwise).  The levels
+        become available as self.ml.levels for the work model; they are NOT uploaded to the GPU (flows that need
+        them there call setup() without defer_coarse_levels)."""
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            return
+        t0 = time.time()
+        ml, _, used = pending.result()
+        self._pending = None
+        self._pending_pool.shutdown(wait=False)
+        self.setup_log["host_levels_wait_s"] = round(time.time() - t0, 4)
+        if self._pending_ckey is not None:
+            _cache.save(self._cache_dir, "mgtv", self._pending_ckey,
+                        {"tv%d" % i: np.asarray(v) for i, v in enumerate(used)})
+        lev0 = self.ml.levels[0]
+        ml.levels[0].A = lev0.A          # (the same operator object the callers hold)
+        self.ml = ml
+        self.testvectors = used
+        self.total_levels = len(ml.levels)
+        self.A = ml.levels[0].A
+        self._coarse_levels_on_host_only = True
 
     def _device_reference_hierarchy(self, dof, aggrs, max_levels, acc_eigvs, params, tv):
         """hierarchy.reference_hierarchy with the eigensolves of the lattice level on the GPU.  Rank 0 runs
@@ -589,6 +677,9 @@ class MG:
 
     def __str__(self):
         out = "\nMultilevel information:\n"
+        if getattr(self, "_pending", None) is not None:
+            return out + "Level: 0\n\tsize(A) = " + str(self.ml.levels[0].A.shape) + \
+                "\n(coarse levels: under construction on a host thread, MG.finish_setup() joins it)\n"
         last = len(self.ml.levels) - 1
         for idx, level in enumerate(self.ml.levels):
             out += "Level: " + str(idx) + "\n"

@@ -177,8 +177,11 @@ def run_probe_loop(evaluate, n, level_tol, max_nr_ests, batch, comm=None, min_in
             "solved": int(ests.size)}
 
 
-def _setup_solver(A, params, announce=True):
+def _setup_solver(A, params, announce=True, defer_coarse=False):
     mg_solver = MG(A)
+    if defer_coarse and "defer_coarse_levels" not in params:
+        # build-only: the flow uses level 0 only until its work model at the very end (MG.finish_setup)
+        params = dict(params, defer_coarse_levels=True)
     mg_solver.coarsest_iters = 0
     mg_solver.coarsest_iters_tot = 0
     mg_solver.coarsest_iters_avg = 0
@@ -190,15 +193,17 @@ def _setup_solver(A, params, announce=True):
                     sys_type=params['problem_name'], params=params)
     print(" done. Time : " + str(time.time() - t0) + " seconds")
     print(mg_solver)
-    nr_levels = len(mg_solver.ml.levels)
+    deferred = getattr(mg_solver, "_pending", None) is not None
+    nr_levels = mg_solver.total_levels if deferred else len(mg_solver.ml.levels)
     mg_solver.total_levels = nr_levels
     for i in range(nr_levels):
         mg_solver.coarsest_lev_iters[i] = 0
     if nr_levels < 3:
         raise Exception("Use three or more levels.")
-    for i in range(nr_levels - 1):
-        mg_solver.ml.levels[i].P = csr_matrix(mg_solver.ml.levels[i].P)
-        mg_solver.ml.levels[i].R = csr_matrix(mg_solver.ml.levels[i].R)
+    if not deferred:
+        for i in range(nr_levels - 1):
+            mg_solver.ml.levels[i].P = csr_matrix(mg_solver.ml.levels[i].P)
+            mg_solver.ml.levels[i].R = csr_matrix(mg_solver.ml.levels[i].R)
     return mg_solver, nr_levels
 
 
@@ -216,7 +221,7 @@ def _rough_trace(mg_solver, params, n, Vx_rank, tr1):
 
 # compute tr(A^{-1}) via (deflated) Hutchinson                      stoch_trace.py:33-179
 def hutchinson(A, params):
-    mg_solver, nr_levels = _setup_solver(A, params)
+    mg_solver, nr_levels = _setup_solver(A, params, defer_coarse=True)
     N = A.shape[0]
     batch = int(params.get('batch', DEFAULT_BATCH))
 
@@ -254,6 +259,7 @@ def hutchinson(A, params):
 
     function_iters = int(np.sum(loop["iters_fine"]))
     mg_solver.coarsest_lev_iters[0] = function_iters
+    mg_solver.finish_setup()          # the coarse levels (built beside the probe loop): the work model reads their nnz
     result = dict()
     result['trace'] = loop["avg"] + tr1
     result['std_dev'] = loop["dev"]

@@ -61,7 +61,7 @@ _MLMC_KEYS = ('mlmc_deflat_vctrs', 'defl_eigvs_tol_MLMC', 'diff_lev_op_tol', 'de
 _BUILD_KEYS = ('batch', 'device', 'engines', 'cache_dir', 'report_path', 'probe_type', 'solver_cfg', 'use_solver_hierarchy', 'mg_testvectors',
                'solver_testvectors', 'deflation_eigenpairs', 'ref_cycle_post', 'ref_cycle_k', 'ref_smoother',
                'solver_restart', 'stochastic_coarsest', 'stop_factor', 'ref_direct_max_n', 'ref_coarsest',
-               'ref_coarse_dofs',
+               'ref_coarse_dofs', 'setup_eigs', 'defer_coarse_levels',
                'verbose', 'probe_rounds_max')
 
 

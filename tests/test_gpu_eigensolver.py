@@ -128,3 +128,31 @@ def test_device_eigenpairs_match_arpack_on_schwinger128():
     print("tr1 device %r golden %r" % (tr1, tr1_gold))
     assert abs(tr1 - tr1_gold) / abs(tr1_gold) < 1e-8
     eng.close()
+
+
+def test_hutchinson_flow_with_deferred_coarse_levels_gives_the_same_result():
+    """stoch_trace.hutchinson builds the coarse levels of the reference hierarchy on a host thread WHILE the
+    probes run (MG.setup with defer_coarse_levels, joined by MG.finish_setup for the work model): same trace,
+    stopping index, iteration total and complexity figure as with the levels built up front; and the device
+    setup (eigensolves on the GPU) against the reference's host ARPACK setup: same stopping index, traces equal
+    to 1e-7 (two eigensolvers at 1e-9 behind the deflation vectors)."""
+    import contextlib
+    import io
+    from deflatedmlmc_schwinger_amd import stoch_trace
+    params = gateway.set_params('schwinger128')
+    params['function_tol'] = 1e-12
+    A = matrix.loadMatrix(params['matrix'], params['matrix_params'])
+    out = {}
+    for key, extra in (("deferred", {}), ("upfront", {"defer_coarse_levels": False}),
+                       ("reference", {"setup_eigs": "reference"})):
+        tp = utils.trace_params_from_params(dict(params, **extra), "hutchinson")
+        tp.update(extra)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out[key] = stoch_trace.hutchinson(A, tp)
+    a, b, c = out["deferred"], out["upfront"], out["reference"]
+    assert a['nr_ests'] == b['nr_ests'] == c['nr_ests']
+    assert a['function_iters'] == b['function_iters']
+    assert abs(a['trace'] - b['trace']) <= 1e-12 * abs(b['trace'])
+    assert a['total_complexity'] == b['total_complexity']
+    assert abs(a['trace'] - c['trace']) <= 1e-7 * abs(c['trace'])
+    assert abs(a['total_complexity'] - c['total_complexity']) <= 1e-3 * c['total_complexity']

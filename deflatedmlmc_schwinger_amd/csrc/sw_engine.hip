@@ -3912,7 +3912,7 @@ int sw_eig_gram(sw_engine* h, int a, int b, double* out) {
   }
   {
     LaunchScope ls(h, T_DOTS);
-    hipLaunchKernelGGL(swk::k_block_gram_reduce, dim3(16), dim3(SW_BLOCK), 0, h->stream,
+    hipLaunchKernelGGL(swk::k_block_gram_reduce, dim3(64), dim3(64), 0, h->stream,
                        (const cplx*)h->partial, P, h->eig_small);
     KLAUNCH_CHECK();
   }

@@ -3000,9 +3000,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_block_gram_reduce(const cplx* __re
                                                                 cplx* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 4096) return;
-  cplx s = cmake(0.0, 0.0);
-  for (int p = 0; p < P; ++p) s = cadd(s, partial[(size_t)p * 4096 + e]);
-  out[e] = s;
+  // four interleaved partial sums (a fixed tree: deterministic), so that four loads are in flight per thread
+  cplx s0 = cmake(0.0, 0.0), s1 = s0, s2 = s0, s3 = s0;
+  int p = 0;
+  for (; p + 3 < P; p += 4) {
+    s0 = cadd(s0, partial[(size_t)p * 4096 + e]);
+    s1 = cadd(s1, partial[(size_t)(p + 1) * 4096 + e]);
+    s2 = cadd(s2, partial[(size_t)(p + 2) * 4096 + e]);
+    s3 = cadd(s3, partial[(size_t)(p + 3) * 4096 + e]);
+  }
+  for (; p < P; ++p) s0 = cadd(s0, partial[(size_t)p * 4096 + e]);
+  out[e] = cadd(cadd(s0, s1), cadd(s2, s3));
 }
 
 // out[row][j] = sum_i W[row][i] Y[i][j]; Y in LDS (64 KB), one wave per row, lane = j

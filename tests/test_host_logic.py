@@ -238,6 +238,43 @@ def test_estimator_option_validation(A16):
         hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], 3, 'medium', tp)
 
 
+def test_reference_hierarchy_eigensolver_hook_and_deferred_inverse(A16):
+    """hierarchy.reference_hierarchy's hooks for the device setup: `eigs_fn(level, A_l, nvec, tol)` supplies the
+    test vectors of the levels it answers for (None = the reference's own ARPACK call), a partial `testvectors`
+    list pins the levels it names, `invert=False` leaves the coarsest inverse to the engine -- the hierarchy built
+    through the hooks from the SAME vectors equals the plain one entry for entry."""
+    p = gateway.set_params('schwinger16')
+    p['function_tol'] = 1e-12
+    tp = utils.trace_params_from_params(p, "mlmc")
+    ml, cinv, tv = hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], tp['max_nr_levels'],
+                                                 tp['accuracy_mg_eigvs'], tp)
+    calls = []
+
+    def eigs_fn(level, Al, nvec, tol):
+        calls.append((level, Al.shape[0], nvec, tol))
+        return tv[level] if level == 0 else None          # level 0 from the "device", the rest from ARPACK
+
+    ml2, cinv2, tv2 = hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], tp['max_nr_levels'],
+                                                    tp['accuracy_mg_eigvs'], tp, eigs_fn=eigs_fn, invert=False)
+    assert cinv2 is None and cinv is not None
+    assert [c[0] for c in calls] == list(range(tp['max_nr_levels'] - 1))
+    assert calls[0][1:] == (A16.shape[0], int(tp['dof'][1] / 2), 1.0e-3)
+    assert np.array_equal(np.asarray(tv2[0]), np.asarray(tv[0]))
+    assert abs(ml2.levels[1].A - ml.levels[1].A).max() == 0.0          # same vectors, same arithmetic
+    # a partial list of test vectors pins level 0 only
+    ml3, _, tv3 = hierarchy.reference_hierarchy(A16, tp['dof'], tp['aggrs'], tp['max_nr_levels'],
+                                                tp['accuracy_mg_eigvs'], tp, testvectors=[tv[0]])
+    assert len(tv3) == tp['max_nr_levels'] - 1 and abs(ml3.levels[1].A - ml.levels[1].A).max() == 0.0
+    # the lazy attribute: without an engine the MG object hands back what was set
+    from deflatedmlmc_schwinger_amd.multigrid import MG
+    mg = MG(A16)
+    assert mg.coarsest_inv == []
+    mg.coarsest_inv = cinv
+    assert mg.coarsest_inv is cinv
+    mg.coarsest_inv = None
+    assert mg.coarsest_inv is None
+
+
 def test_product_fails_loudly_without_gpu(A16):
     """no CPU fallback: without a HIP device the product path raises."""
     if device_count() > 0:

@@ -70,6 +70,8 @@ def main(out, extra=""):
                     "k_schur_step<cplx, 2>": "k_schur_step",
                     "k_schur_step<cplx >": "k_schur_step",
                     "k_schur_step<cplx, 0>": "k_schur_step<0/1> (S x, b' - S x)",
+                    "k_dense_mfma3_lds<4>": "k_bsr_mfma(dense coarsest)",
+                    "k_dense_mfma3_lds<2>": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma3<0, 1, false, 8>": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma3<0, 2, false, 8>": "k_bsr_mfma(dense coarsest)",
                     "k_bsr_mfma3<3, 1, true": "k_bsr_mfma(level-1 operator)",

@@ -30,8 +30,8 @@ os.environ.setdefault("OMP_NUM_THREADS", "1")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (dense); measured pure-issue
-                                # ceiling of v_mfma_f64_16x16x4 is 48 TF/s (profiles/)
+MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (dense)
+MFMA_F64_MEASURED_ISSUE_TFLOPS = 48.1   # pure-issue rate of v_mfma_f64_16x16x4, 4 waves per SIMD (profiles/r01_mfma_f64_rate.txt)
 
 
 def parse():
@@ -284,8 +284,13 @@ def kernel_rooflines(eng, levels, V, nbp, pmc=None, skip=(), three_products=True
             rec["bound_detail"] = ("hbm+infinity-cache (working set %.0f MB <= 256 MB: cache-resident rate)"
                                    % (ws / 1e6)) if ws <= 256e6 else "hbm (working set %.0f MB)" % (ws / 1e6)
         if bound == "mfma" and three_products:
-            # k_bsr_mfma3 executes 6 real flops per complex multiply-add, `achieved` counts 8
+            # the three-product kernels execute 6 real flops per complex multiply-add, `achieved` counts 8
             rec["executed_frac_of_peak"] = rec["frac"] * 0.75
+            # what v_mfma_f64_16x16x4 sustains on this chip when NOTHING but it is issued (tools/mfma_f64_rate.hip,
+            # profiles/r01_mfma_f64_rate.txt: 35.8 / 47.4 / 48.1 TFLOP/s at 1 / 2 / 4 waves per SIMD -- 105
+            # 2.4-GHz cycles per instruction against the datasheet's 64): the executed rate against THAT ceiling
+            rec["measured_issue_ceiling_TFLOPs"] = MFMA_F64_MEASURED_ISSUE_TFLOPS
+            rec["executed_frac_of_measured_issue_ceiling"] = (ach * 0.75) / MFMA_F64_MEASURED_ISSUE_TFLOPS
         out.append(rec)
     out.sort(key=lambda r: -r["step_ms"])
     return out

@@ -629,20 +629,20 @@ static int launch_bsr(sw_engine* h, const EllOp& op, int mode, const cplx* X, co
   LaunchScope ls(h, cls);
   // 16 rows x 4 columns x nbp probes x 8 flops per complex multiply-add, per (tile, k-step)
   if (h->profiling) h->twork[cls] += 512.0 * (double)RT * (double)op.bsr_KS * (double)nbp;
+  const int dl_kb = 4;     // k-steps per LDS stage (8 measured 135.1 us against 136.4: barriers are not the bound)
   if (h->mfma_3m && h->dense_lds > 0 && cat == T_COARSEST && mode == 0 && op.dense_uniform &&
-      RT % h->dense_lds == 0 && op.bsr_KS % (SW_DL_KB * SW_DL_DEPTH) == 0 && op.bsr_KS >= 2 * SW_DL_KB * SW_DL_DEPTH &&
+      RT % h->dense_lds == 0 && op.bsr_KS % (dl_kb * SW_DL_DEPTH) == 0 && op.bsr_KS >= 2 * dl_kb * SW_DL_DEPTH &&
       (nbp & 31) == 0 && X != Y) {
     // dense operator: operands shared through LDS (register-staged, double-buffered), one workgroup per
     // (16 dense_lds)-row x 32-probe block -- 1 KiB (0.75 KiB) per wave and k-step through the L2 -> CU path
     // instead of 2
-    if (h->dense_lds == 4)
-      hipLaunchKernelGGL((swk::k_dense_mfma3_lds<4>), dim3((RT / 4) * (nbp / 32)), dim3(512), 0, h->stream,
-                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, Y, nbp,
-                         (const int*)op.bsr_tmap);
-    else
-      hipLaunchKernelGGL((swk::k_dense_mfma3_lds<2>), dim3((RT / 2) * (nbp / 32)), dim3(256), 0, h->stream,
-                         (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, Y, nbp,
-                         (const int*)op.bsr_tmap);
+#define DL_LAUNCH(RTW_, KB_)                                                                                \
+  hipLaunchKernelGGL((swk::k_dense_mfma3_lds<RTW_, KB_>), dim3((RT / RTW_) * (nbp / 32)), dim3(128 * RTW_), 0, \
+                     h->stream, (const cplx*)op.bsr_vals, (const int*)op.bsr_kcol, op.bsr_KS, RT, X, Y, nbp,  \
+                     (const int*)op.bsr_tmap)
+    if (h->dense_lds == 4) DL_LAUNCH(4, 4);
+    else DL_LAUNCH(2, 4);
+#undef DL_LAUNCH
     KLAUNCH_CHECK();
     return 0;
   }

@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(SW_BLOCK, SW_BSR3_MIN_WAVES(NT, STG)) void k_bsr_mf
 // on 256 probes).  Here a workgroup of 2 RTW waves computes a (16 RTW)-row x 32-probe block (RTW row tiles x 2
 // probe tiles, one pair per wave): per k-step it needs RTW KiB of A and 2 KiB of X for all its waves -- 1 KiB
 // (RTW = 2) or 0.75 KiB (RTW = 4) per wave and k-step -- fetched once and shared through LDS.
-// Staging: stages of 4 k-steps; every wave owns PPW of a stage's 1-KiB pieces (A: one contiguous piece per
+// Staging: stages of KB (4 or 8) k-steps; every wave owns PPW of a stage's 1-KiB pieces (A: one contiguous piece per
 // (row tile, k-step) of the block-row packing as it stands; X: two row pairs x 32 probes per k-step, the rows
 // through kcol -- the same for every row tile of a dense operator, `uniform`), loads them with ordinary
 // global_load_dwordx4 into a register ring SW_DL_DEPTH stages deep (the compiler counts vmcnt itself), writes
@@ -1072,18 +1072,17 @@ __global__ __launch_bounds__(SW_BLOCK, SW_BSR3_MIN_WAVES(NT, STG)) void k_bsr_mf
 // (First form, r04i: the same tiling fed by a six-slot ring of LDS-DMA fills, no registers involved --
 // bit-identical and no faster than k_bsr_mfma3, 151 against 146 us: the LDS-DMA path of a CU sustains ~25 GB/s,
 // MI355X_MICROARCH.md "ldsdma-fill", below the 37 GB/s this tiling needs at the full matrix rate.)
-// MODE 0 (Y = A X).  RT % RTW == 0, KS % 16 == 0, nbp % 32 == 0.
+// MODE 0 (Y = A X).  RT % RTW == 0, KS % (4 KB) == 0, nbp % 32 == 0.
 // ------------------------------------------------------------------------------------------
-#define SW_DL_KB 4
 #define SW_DL_DEPTH 4
 
-template <int RTW>
+template <int RTW, int KB>
 __global__ __launch_bounds__(128 * RTW) void k_dense_mfma3_lds(const cplx* __restrict__ Ap,
                                                               const int* __restrict__ kcol, int KS, int RT,
                                                               const cplx* __restrict__ X, cplx* __restrict__ Y,
                                                               int nbp, const int* __restrict__ tmap) {
   constexpr int WAVES = 2 * RTW;
-  constexpr int APIECES = RTW * SW_DL_KB, PIECES = APIECES + 2 * SW_DL_KB, PPW = PIECES / WAVES;
+  constexpr int APIECES = RTW * KB, PIECES = APIECES + 2 * KB, PPW = PIECES / WAVES;
   static_assert(PIECES % WAVES == 0, "pieces must divide over the waves");
   __shared__ cplx lds[2][PIECES * 64];
   const int lane = threadIdx.x & 63;
@@ -1102,20 +1101,22 @@ __global__ __launch_bounds__(128 * RTW) void k_dense_mfma3_lds(const cplx* __res
   const int rtl = wave >> 1, ptl = wave & 1;
   const int rt0 = rb * RTW;
   const int c0 = pc * 32;
-  const int nstages = KS / SW_DL_KB;
+  const int nstages = KS / KB;
   // this wave's pieces of a stage: p = wave + WAVES t.  p < APIECES: A piece (row tile p / KB, k-step p % KB);
   // else X piece q = p - APIECES (k-step q >> 1, row pair q & 1; lane -> row lane >> 5, probe lane & 31).
   // APIECES is a multiple of WAVES, so whether piece t is an A or an X piece is known at compile time.
   // (Everything per piece is a separately named scalar: arrays indexed by t ended up in scratch memory.)
-  static_assert(APIECES % WAVES == 0 && (PPW == 3 || PPW == 4), "piece layout");
+  static_assert(APIECES % WAVES == 0 && PPW >= 3 && PPW <= 6, "piece layout");
 #define SW_DL_SRC(T)                                                                                     \
   ((WAVES * (T) < APIECES)                                                                               \
-       ? Ap + ((size_t)(rt0 + (wave + WAVES * (T)) / SW_DL_KB) * KS + ((wave + WAVES * (T)) % SW_DL_KB)) * 64 + lane \
+       ? Ap + ((size_t)(rt0 + (wave + WAVES * (T)) / KB) * KS + ((wave + WAVES * (T)) % KB)) * 64 + lane \
        : X + (size_t)(2 * ((wave + WAVES * (T) - APIECES) & 1) + (lane >> 5)) * nbp + c0 + (lane & 31))
   const cplx* const src0 = SW_DL_SRC(0);
   const cplx* const src1 = SW_DL_SRC(1);
   const cplx* const src2 = SW_DL_SRC(2);
-  const cplx* const src3 = (PPW == 4) ? SW_DL_SRC(3) : src2;
+  const cplx* const src3 = (PPW > 3) ? SW_DL_SRC(3) : src2;
+  const cplx* const src4 = (PPW > 4) ? SW_DL_SRC(4) : src2;
+  const cplx* const src5 = (PPW > 5) ? SW_DL_SRC(5) : src2;
 #undef SW_DL_SRC
   // k-step (inside a stage) of an X piece
 #define SW_DL_XK(T) ((wave + WAVES * (T) - APIECES) >> 1)
@@ -1125,25 +1126,34 @@ __global__ __launch_bounds__(128 * RTW) void k_dense_mfma3_lds(const cplx* __res
   else DST = SRC[(size_t)kcol[(KS0) + SW_DL_XK(T)] * nbp];
 #define SW_DL_LOAD(RING, ST)                                                                       \
   {                                                                                                \
-    const int ks0_ = min((ST), nstages - 1) * SW_DL_KB;                                            \
+    const int ks0_ = min((ST), nstages - 1) * KB;                                                  \
     SW_DL_LD1(RING##_0, src0, 0, ks0_)                                                             \
     SW_DL_LD1(RING##_1, src1, 1, ks0_)                                                             \
     SW_DL_LD1(RING##_2, src2, 2, ks0_)                                                             \
-    if (PPW == 4) { SW_DL_LD1(RING##_3, src3, 3, ks0_) }                                           \
+    if (PPW > 3) { SW_DL_LD1(RING##_3, src3, 3, ks0_) }                                            \
+    if (PPW > 4) { SW_DL_LD1(RING##_4, src4, 4, ks0_) }                                            \
+    if (PPW > 5) { SW_DL_LD1(RING##_5, src5, 5, ks0_) }                                            \
   }
 #define SW_DL_WRITE(RING, BUF)                                                                     \
   {                                                                                                \
     lds[BUF][(wave + WAVES * 0) * 64 + lane] = RING##_0;                                           \
     lds[BUF][(wave + WAVES * 1) * 64 + lane] = RING##_1;                                           \
     lds[BUF][(wave + WAVES * 2) * 64 + lane] = RING##_2;                                           \
-    if (PPW == 4) lds[BUF][(wave + WAVES * 3) * 64 + lane] = RING##_3;                             \
+    if (PPW > 3) lds[BUF][(wave + WAVES * 3) * 64 + lane] = RING##_3;                              \
+    if (PPW > 4) lds[BUF][(wave + WAVES * 4) * 64 + lane] = RING##_4;                              \
+    if (PPW > 5) lds[BUF][(wave + WAVES * 5) * 64 + lane] = RING##_5;                              \
   }
-  cplx ring0_0, ring0_1, ring0_2, ring0_3 = cmake(0.0, 0.0), ring1_0, ring1_1, ring1_2, ring1_3 = ring0_3;
-  cplx ring2_0, ring2_1, ring2_2, ring2_3 = ring0_3, ring3_0, ring3_1, ring3_2, ring3_3 = ring0_3;
+#define SW_DL_DECL(RING) \
+  cplx RING##_0, RING##_1, RING##_2, RING##_3 = cmake(0.0, 0.0), RING##_4 = RING##_3, RING##_5 = RING##_3;
+  SW_DL_DECL(ring0)
+  SW_DL_DECL(ring1)
+  SW_DL_DECL(ring2)
+  SW_DL_DECL(ring3)
+#undef SW_DL_DECL
   static_assert(SW_DL_DEPTH == 4, "the ring is written out for four stages");
   // one stage: stage ST + 1 (held in RING) into the other LDS buffer -- everybody left it at the barrier that
   // ended stage ST - 1; after the last stage this writes a re-loaded stage nobody reads --, RING refilled with
-  // stage ST + 5, then the four k-steps of stage ST from buffer BUF.  (The fences: hipcc otherwise sinks the
+  // stage ST + 5, then the KB k-steps of stage ST from buffer BUF.  (The fences: hipcc otherwise sinks the
   // refill loads down to their use four stages later and the ring collapses to one stage in flight.)
 #define SW_DL_STEP(RING, BUF, ST)                                                                  \
   {                                                                                                \
@@ -1152,7 +1162,7 @@ __global__ __launch_bounds__(128 * RTW) void k_dense_mfma3_lds(const cplx* __res
     SW_DL_LOAD(RING, (ST) + 1 + SW_DL_DEPTH);                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     const cplx* sl_ = &lds[BUF][0];                                                                \
-    _Pragma("unroll") for (int k = 0; k < SW_DL_KB; ++k) {                                         \
+    _Pragma("unroll") for (int k = 0; k < KB; ++k) {                                               \
       const cplx m_ = sl_[a_off + k * 64];                                                         \
       const cplx xv_ = sl_[x_off + k * 128];                                                       \
       t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m_.x, xv_.x, t1, 0, 0, 0);                         \
@@ -1174,9 +1184,9 @@ __global__ __launch_bounds__(128 * RTW) void k_dense_mfma3_lds(const cplx* __res
   sw_double4 t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1, t3 = t1;
   // fragment offsets inside a stage buffer: A piece (rtl KB + k) -> [lane]; X pieces (APIECES + 2 k + (row >> 1)) ->
   // [(row & 1) 32 + probe], row = lane >> 4, probe = ptl 16 + (lane & 15)
-  const int a_off = (rtl * SW_DL_KB) * 64 + lane;
+  const int a_off = (rtl * KB) * 64 + lane;
   const int x_off = (APIECES + (lane >> 5)) * 64 + ((lane >> 4) & 1) * 32 + ptl * 16 + (lane & 15);
-  // nstages % 4 == 0 (the launcher checks KS % 16 == 0); stage st + 1 sits in ring (st + 1) % 4
+  // nstages % 4 == 0 (the launcher checks KS % (4 KB) == 0); stage st + 1 sits in ring (st + 1) % 4
   for (int st = 0; st < nstages; st += 4) {
     SW_DL_STEP(ring1, 0, st);
     SW_DL_STEP(ring2, 1, st + 1);

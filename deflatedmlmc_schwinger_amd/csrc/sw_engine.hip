@@ -3346,8 +3346,27 @@ int sw_setup_eo_operators(sw_engine* h, int hid, int level, int Lc) {
         return sw_fail(h, "level %d: not a nearest-neighbour operator with the own site last", level);
       nbr[(size_t)s * 5 + j] = t;
     }
+  // The row tiles of the four operators are listed -- i.e. WALKED by the block-row kernel, XCD band by XCD band --
+  // in lattice tiles of 16 x 16 sites (SW_EO_WALK_TILE) on lattices of 32 x 32 sites and more: a row of S reads the x tiles of nine
+  // sites, and in plain lattice order the neighbours in y are a whole lattice row of x tiles apart (128 sites x
+  // 32 KiB = 4 MB at 128 probes: the size of an XCD's L2), so they came from the fabric every time -- 2.73 GB
+  // fetched per launch of the 262144-row level's Schur step against 0.84 GB algorithmic
+  // (profiles/kernel_pmc_1024.json).  An 8 x 8 tile with its halo is 3.2 MB of x.  (Output tiles go through tmap,
+  // columns through kcol: the order of the list is free.)
+  std::vector<int> walk(ns);
+  for (int s = 0; s < ns; ++s) walk[s] = s;
+  if (Lc >= 32 && Lc % 16 == 0) {
+    const char* te_ = std::getenv("SW_EO_WALK_TILE");
+    // (1024^2, 128 probes, strict: lattice order 508.7 probe-samples/s, tiles of 4 / 8 / 16 sites 512.7 / 515.1 / 521.3;
+    // the Schur step of the 262144-row level 395 -> 342 us and 2.73 -> 1.90 GB fetched with 8: r04r / r04s)
+    const int T = (te_ && std::atoi(te_) > 0 && Lc % std::atoi(te_) == 0) ? std::atoi(te_) : 16, tpr = Lc / T;
+    std::stable_sort(walk.begin(), walk.end(), [&](int a, int b) {
+      const int ta = ((a / Lc) / T) * tpr + (a % Lc) / T, tb = ((b / Lc) / T) * tpr + (b % Lc) / T;
+      return ta < tb;
+    });
+  }
   std::vector<int> E, O, rank(ns);
-  for (int s = 0; s < ns; ++s) {
+  for (int s : walk) {
     std::vector<int>& v = parity(s) ? O : E;
     rank[s] = (int)v.size();
     v.push_back(s);

@@ -359,8 +359,10 @@ static int sw_fail(sw_engine* h, const char* fmt, ...) {
 // lattice), and in a process that has already moved ~100 GB through the allocator those calls were measured at
 // 2.5-3.4 s per setup where a fresh process needs 0.02 s (profiles/r04_ab_sessions.txt, r04h: the cause of the
 // driver-observed 2.4x slower 1024^2 setup of round 3).  The pool is per process (engines come and go), capped
-// (SW_POOL_GB, default 48; 0 disables), and a block is parked only after the freeing engine's streams have
-// drained (hipFree's implicit synchronisation is what made reuse by another stream safe before).
+// (SW_POOL_GB, default 128 of the 288 GB: evicting parked blocks is itself a slow hipFree; 0 disables; an
+// allocation that fails with blocks parked returns them to the driver and retries), and a block is parked only
+// after the freeing engine's streams have drained (hipFree's implicit synchronisation is what made reuse by
+// another stream safe before).
 namespace {
 struct ParkedBlock {
   void* p;
@@ -374,7 +376,7 @@ const size_t kPoolMinBlock = (size_t)32 << 20;
 size_t pool_cap() {
   static const size_t cap = [] {
     const char* e = std::getenv("SW_POOL_GB");
-    const double gb = e ? std::atof(e) : 48.0;
+    const double gb = e ? std::atof(e) : 128.0;
     return gb > 0.0 ? (size_t)(gb * 1073741824.0) : (size_t)0;
   }();
   return cap;
@@ -409,7 +411,19 @@ static int dev_alloc(sw_engine* h, void** p, size_t bytes) {
       h->pool_hits++;
     }
   }
-  if (!*p) HIPCHK(hipMalloc(p, bytes));
+  if (!*p && hipMalloc(p, bytes) != hipSuccess) {
+    // out of device memory with blocks parked: give them back and try once more
+    (void)hipGetLastError();
+    std::vector<ParkedBlock> blocks;
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      blocks.swap(g_pool);
+      g_pool_bytes = 0;
+    }
+    for (auto& b : blocks) (void)hipFree(b.p);
+    *p = nullptr;
+    HIPCHK(hipMalloc(p, bytes));
+  }
   h->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   h->alloc_calls++;
   h->alloc_bytes += (double)bytes;

@@ -43,7 +43,8 @@ const char* sw_last_error(sw_engine* h);          /* h may be NULL: last create(
 int sw_device_count(void);                         /* 0 when no GPU is visible            */
 /* Device blocks of 32 MB and more that an engine frees (setup scratch, workspaces, everything at sw_destroy)
  * are parked in a process-wide pool and handed out again instead of going back to the driver (cap SW_POOL_GB,
- * default 48 GB; 0 disables): sw_pool_trim() releases what is parked. */
+ * default 128 GB; 0 disables; an allocation that fails with blocks parked releases them and retries):
+ * sw_pool_trim() releases what is parked. */
 int sw_pool_trim(void);
 const char* sw_version(void);
 

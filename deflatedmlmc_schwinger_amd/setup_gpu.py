@@ -9,6 +9,7 @@ where SuperLU on the host is impractical.  Galerkin products and the per-aggrega
 the host (SciPy / NumPy).
 """
 import sys
+import os
 import time
 
 import numpy as np
@@ -113,11 +114,17 @@ def level_geometry(Lf, hd, agg, fine_level):
     pos_of = np.empty(n, dtype=np.int64)
     blk_of[blk_rows] = np.arange(nblocks)[:, None]
     pos_of[blk_rows] = np.arange(rpb)[None, :]
-    G = 4 if fine_level else 8
-    ng = n // G
-    rb = blk_of.reshape(ng, G)
-    b0, b1 = rb.min(axis=1), rb.max(axis=1)
-    if not ((rb == b0[:, None]) | (rb == b1[:, None])).all():
+    # rows per group of the prolongator.  Level 0: 8 consecutive rows = four sites of one parity along x, both
+    # spins, where they stay inside one aggregate (aggregate edges that are multiples of 8): the group's 16 coarse
+    # rows are then pulled through the L2 once per 8 fine rows instead of once per 4 (k_ell<8,0> 30 us against
+    # k_ell<4,0> 35 us per launch at 128^2 x 256 probes, profiles/r04_ab_sessions.txt r04aa); else 4 (two sites)
+    for G in ((int(os.environ.get("SW_P_GROUP0", "8")), 4) if fine_level else (8,)):
+        ng = n // G
+        rb = blk_of.reshape(ng, G)
+        b0, b1 = rb.min(axis=1), rb.max(axis=1)
+        if ((rb == b0[:, None]) | (rb == b1[:, None])).all():
+            break
+    else:
         raise Exception("a row group of the prolongator touches more than two blocks")
     two = bool((b0 != b1).any())
     K = 16 if two else 8

@@ -748,10 +748,24 @@ __global__ __launch_bounds__(SW_BLOCK) void k_ell(const int* __restrict__ cols,
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = czero<C>();
   const C* Xc = X + col;
-#pragma unroll 4
-  for (int k = 0; k < K; ++k) {
-    const int j = c[k];
-    const C x = Xc[(size_t)j * nbp];
+  // eight X rows requested at a time, then their G x 8 multiply-adds (coefficients are scalar loads): left to
+  // itself the compiler keeps two row loads in flight and a K = 32 group pays sixteen round trips (the restrictor
+  // of the lattice level: 23 us per launch for 75 MB).  Same order of the sums per row.
+  constexpr int UC = (G <= 8) ? 8 : 4;
+  int k = 0;
+  for (; k + UC <= K; k += UC) {
+    C xs[UC];
+#pragma unroll
+    for (int u = 0; u < UC; ++u) xs[u] = Xc[(size_t)c[k + u] * nbp];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) cfma(acc[g], v[(size_t)(k + u) * G + g], xs[u]);
+    }
+  }
+  for (; k < K; ++k) {
+    const C x = Xc[(size_t)c[k] * nbp];
 #pragma unroll
     for (int g = 0; g < G; ++g) cfma(acc[g], v[(size_t)k * G + g], x);
   }

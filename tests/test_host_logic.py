@@ -348,13 +348,16 @@ def test_singular_vector_test_vectors_give_a_g3_compatible_hierarchy(A16, tv_typ
     assert abs(abs(lam) - smin) < 1e-6 * smin + 1e-9 or abs(lam) < 10 * smin
 
 
-@pytest.mark.parametrize("Lf,hd,agg,fine", [(16, 1, 4, True), (8, 8, 2, False), (16, 8, 4, False)])
+@pytest.mark.parametrize("Lf,hd,agg,fine", [(16, 1, 4, True), (32, 1, 8, True), (8, 8, 2, False),
+                                            (16, 8, 4, False)])
 def test_device_setup_geometry_reproduces_the_host_prolongator(Lf, hd, agg, fine):
     """setup_gpu.level_geometry (block membership + grouped-ELL structure handed to
     sw_setup_transfer) against hierarchy._site_prolongator: with the same per-block Q the
-    prolongator is identical entry for entry."""
+    prolongator is identical entry for entry.  Lattice level: groups of 8 fine rows where four sites of
+    one parity along x stay inside an aggregate (edge 8), groups of 4 otherwise (edge 4)."""
     from deflatedmlmc_schwinger_amd import setup_gpu
     g = setup_gpu.level_geometry(Lf, hd, agg, fine)
+    assert g["G"] == ((8 if agg % 8 == 0 else 4) if fine else 8)
     n = 2 * Lf * Lf * hd
     rng = np.random.default_rng(1)
     tv = rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8))

@@ -37,8 +37,10 @@ MFMA_F64_MEASURED_ISSUE_TFLOPS = 48.1   # pure-issue rate of v_mfma_f64_16x16x4,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (defaults = what the round driver passes: with 4 steps after ONE warm-up batch the first timed batches still
+    # carry first-use costs -- 7.7 ms per step against 7.1-7.2 over 20 steps after 5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nb", type=int, default=256, help="probes per engine stream per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SW_STREAMS", "0")),
                     help="concurrent probe batches (engine handles / HIP streams) per GPU; one since round "
